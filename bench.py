@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mcells/s of the 3-D FDTD time-stepping hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NS|C2|C3|C4|C5]
+
+One bench "step" = `--ts-per-step` (default 100) full FDTD timesteps (E half-step + H half-step incl.
+CPML, source, port probes and NF2FF running-DFT surfaces) of the named BASELINE workload; default
+workload is the north-star 300x300x60 patch-on-FR-4 grid with 10-cell CPML, fp32.  Inputs are
+resident in HBM before the timed region.  For N > 1 (launched by torch.distributed.run, one rank
+per GPU) the SAME global grid is z-slab decomposed over the ranks (strong scaling, as BASELINE.json
+states the target) with RCCL halo exchange inside libfdtd_hip.so.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event kernel
+durations of the dominant kernel vs 36 algorithmic bytes per cell per half-step) and, at N = 1,
+`cpu_baseline` (the oracle, test infrastructure, timed on the host cores as a reported non-target).
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "fdtd-solver-antennas_amd"
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md: 8 TB/s; 6.29 TB/s measured copy ceiling)
+ALGO_BYTES_PER_CELL_HALFSTEP = 36.0   # read 3 + 3 field components, write 3 (fp32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="NS")
+    ap.add_argument("--ts-per-step", type=int, default=100)
+    ap.add_argument("--cpml-cells", type=int, default=10)
+    ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "lds"])
+    ap.add_argument("--raw-operator", action="store_true", help="stream 12 coefficient arrays instead of class bytes")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="oracle timesteps for the cpu_baseline leg (0 = auto)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    capi = importlib.import_module(PKG + "._capi")
+    wl = importlib.import_module(PKG + ".workloads")
+    sc = importlib.import_module(PKG + ".scene")
+    simm = importlib.import_module(PKG + ".simulation")
+    hip = capi.load_hip_library()           # raises if the HIP library is missing: no fallback
+
+    w = wl.patch_workload(args.workload)
+    vox = sc.voxelize(w.scene, w.grid)
+    nts_total = (args.steps + args.warmup) * args.ts_per_step * 2 + 8
+    sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=args.cpml_cells,
+                          nr_ts=nts_total, nf2ff_freqs=[w.f0], use_classes=not args.raw_operator)
+    flags = {"auto": capi.FLAG_KERNEL_AUTO, "direct": capi.FLAG_KERNEL_DIRECT, "lds": capi.FLAG_KERNEL_LDS}[args.kernel]
+    eng = sim.build(hip, rank=rank, world=world, device=local_rank, flags=flags)
+    if world > 1:
+        uid = [capi.comm_unique_id(hip) if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    tps = args.ts_per_step
+    for _ in range(args.warmup):
+        eng.run(tps)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run(tps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ncells = w.grid.ncells
+    timesteps = args.steps * tps
+    value = ncells * timesteps / elapsed / 1e6
+
+    # roofline of the dominant kernel (E half-step == H half-step in algorithmic bytes): HIP events on
+    # the engine's own stream around every main-kernel launch, over a second pass of the same length.
+    prof = eng.run_profiled(min(timesteps, 2000))
+    own_cells = eng.nk * eng.ny * eng.nx
+    algo_bytes = ALGO_BYTES_PER_CELL_HALFSTEP * own_cells
+    ms_e, ms_h = prof.ms_update_e, prof.ms_update_h
+    dom = "update_E" if ms_e >= ms_h else "update_H"
+    ms_dom = max(ms_e, ms_h)
+    achieved = algo_bytes / (ms_dom * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": dom, "ms_update_E": round(ms_e, 5), "ms_update_H": round(ms_h, 5),
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "ms_per_timestep_profiled": round(prof.ms_total / prof.steps, 5),
+                "combined_EH_GBs": round(2 * algo_bytes / ((ms_e + ms_h) * 1e-3) / 1e9, 1)}
+    finite = bool(np.isfinite(eng.get_field(0, 2)).all())
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(capi, simm, w, vox, args)
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        out = {
+            "metric": "Mcells/s (Yee cells x steps / s)", "value": round(value, 1), "unit": "Mcells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w.grid.shape[0]}x{w.grid.shape[1]}x{w.grid.shape[2]} "
+                                   f"2.45 GHz patch on FR-4 (fixed scene), CPML-{args.cpml_cells}, lumped port, "
+                                   f"NF2FF DFT surfaces",
+                       "cells": ncells, "timesteps_per_step": tps, "operator": sim.operator_form,
+                       "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
+                       "fields_finite": finite},
+            "roofline": roofline,
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(capi, simm, w, vox, args):
+    """The oracle (plain-C restatement, OpenMP) on a bounded sample of the same workload."""
+    import numpy as np
+    so = os.path.join(ROOT, "oracle", "libfdtd_oracle.so")
+    if not os.path.isfile(so):
+        return None
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    ora = capi.bind(ctypes.CDLL(so))
+    steps = args.cpu_steps or max(10, int(2.0e9 / w.grid.ncells))   # ~2e9 cell-steps: 10-30 s of CPU work
+    sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=args.cpml_cells,
+                          nr_ts=steps + 16, nf2ff_freqs=[w.f0])
+    e = sim.build(ora)
+    rng = np.random.default_rng(0)
+    for kind in (0, 1):        # non-zero start: avoids x86 denormal stalls of the all-zero initial state
+        for c in range(3):
+            e.set_field(kind, c, (1e-3 * rng.standard_normal(e.local_shape)).astype(np.float32))
+    e.run(4)
+    t0 = time.perf_counter()
+    e.run(steps)
+    dt = time.perf_counter() - t0
+    return {"value": round(w.grid.ncells * steps / dt / 1e6, 1), "unit": "Mcells/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{steps} timesteps of the same {w.grid.shape[0]}x{w.grid.shape[1]}x{w.grid.shape[2]} workload "
+                      f"(oracle/libfdtd_oracle.so, OpenMP, seeded non-zero fields), {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

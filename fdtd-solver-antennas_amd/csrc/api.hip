@@ -1,0 +1,690 @@
+// api.hip — C ABI of libfdtd_hip.so (include/fdtd_hip.h): context management, uploads, the
+// time-stepping loop and the z-slab halo exchange (RCCL over xGMI, overlapped with interior updates).
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "fdtd_ctx.h"
+
+static thread_local std::string g_err;
+
+int fdtd_fail(fdtd_ctx* c, int code, const char* fmt, ...) {
+  char buf[768];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_err = buf;
+  return code;
+}
+
+#define NCCLCK(c, expr)                                                                      \
+  do {                                                                                       \
+    ncclResult_t r_ = (expr);                                                                \
+    if (r_ != ncclSuccess)                                                                   \
+      return fdtd_fail(c, FDTD_E_DEVICE, "%s: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+// dense host [rows][nx] -> device [rows][P]
+template <typename T>
+static hipError_t upload_rows(T* dst, int P, const T* src, int nx, size_t rows) {
+  return hipMemcpy2D(dst, (size_t)P * sizeof(T), src, (size_t)nx * sizeof(T), (size_t)nx * sizeof(T), rows, hipMemcpyHostToDevice);
+}
+
+template <typename T>
+static hipError_t to_device(T** dst, const std::vector<T>& v) {
+  hipFree(*dst); *dst = nullptr;
+  hipError_t e = hipMalloc(dst, std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (e != hipSuccess) return e;
+  if (v.empty()) return hipSuccess;
+  return hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+extern "C" {
+
+int fdtd_version(void) { return FDTD_ABI_VERSION; }
+
+int fdtd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* fdtd_backend(void) { return "hip:gfx950"; }
+
+const char* fdtd_last_error(const fdtd_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+static int n_axis(const fdtd_ctx* c, int a) { return a == 0 ? c->d.nx : a == 1 ? c->d.ny : c->d.nk; }
+
+int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
+  if (!d || !out) return fdtd_fail(nullptr, FDTD_E_ARG, "null argument");
+  if (d->nx < 2 || d->ny < 2 || d->nz < 2 || d->nk < 1 || d->k0 < 0 || d->k0 + d->nk > d->nz)
+    return fdtd_fail(nullptr, FDTD_E_ARG, "bad grid/slab %dx%dx%d k0=%d nk=%d", d->nx, d->ny, d->nz, d->k0, d->nk);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fdtd_fail(nullptr, FDTD_E_DEVICE, "no HIP device visible (libfdtd_hip.so has no CPU fallback)");
+  if (d->device < 0 || d->device >= ndev) return fdtd_fail(nullptr, FDTD_E_ARG, "device %d of %d", d->device, ndev);
+  const long P = (d->nx + 3) / 4 * 4;
+  const long plane = P * d->ny;
+  if (plane * (long)(d->nk + 2) >= (1L << 31)) return fdtd_fail(nullptr, FDTD_E_UNSUPPORTED, "slab exceeds 2^31 elements per component");
+  fdtd_ctx* c = new (std::nothrow) fdtd_ctx();
+  if (!c) return fdtd_fail(nullptr, FDTD_E_NOMEM, "ctx");
+  c->d = *d;
+  c->P = (int)P; c->plane = (int)plane; c->nloc = (size_t)plane * d->nk;
+#define CK(expr)                                                                                        \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) {                                                                             \
+      fdtd_fail(nullptr, FDTD_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));                        \
+      fdtd_destroy(c);                                                                                  \
+      return FDTD_E_DEVICE;                                                                             \
+    }                                                                                                   \
+  } while (0)
+  CK(hipSetDevice(d->device));
+  CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  CK(hipEventCreateWithFlags(&c->ev_E, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&c->ev_H, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&c->ev_haloE, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&c->ev_haloH, hipEventDisableTiming));
+  const size_t fbytes = (size_t)plane * (d->nk + 2) * sizeof(float);
+  for (int n = 0; n < 6; ++n) {
+    CK(hipMalloc(&c->fieldbase[n], fbytes));
+    CK(hipMemset(c->fieldbase[n], 0, fbytes));
+  }
+  CK(hipMalloc(&c->d_step, sizeof(long long)));
+  CK(hipMemset(c->d_step, 0, sizeof(long long)));
+  CK(hipMalloc(&c->d_energy, 2 * sizeof(double)));
+  CK(hipMalloc(&c->d_probe, sizeof(DevProbe) * FDTD_MAX_PROBES));
+  CK(hipMalloc(&c->d_box, sizeof(DevBox) * FDTD_MAX_BOXES));
+  CK(hipMalloc(&c->lut, 256 * sizeof(float2)));
+  CK(hipMemset(c->lut, 0, 256 * sizeof(float2)));
+  // a one-sample zero signal so k_post always has a valid pointer
+  CK(hipMalloc(&c->sig, sizeof(float)));
+  CK(hipMemset(c->sig, 0, sizeof(float)));
+  c->nsig = 0;
+#undef CK
+  DevParams& p = c->p;
+  p.nx = d->nx; p.ny = d->ny; p.nk = d->nk; p.P = (int)P; p.P4 = (int)(P / 4);
+  p.plane = (int)plane; p.nloc = (int)c->nloc;
+  for (int n = 0; n < 3; ++n) {
+    p.V[n] = c->fieldbase[n] + plane;
+    p.I[n] = c->fieldbase[3 + n] + plane;
+  }
+  for (int a = 0; a < 3; ++a) { p.pml_lo[a] = 0; p.pml_hi[a] = 1 << 30; p.pml_hi_slot[a] = 0; p.nslot[a] = 0; }
+  choose_tiling(c);
+  *out = c;
+  return FDTD_OK;
+}
+
+void fdtd_destroy(fdtd_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->d.device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
+  if (c->comm) ncclCommDestroy((ncclComm_t)c->comm);
+  for (int n = 0; n < 6; ++n) hipFree(c->fieldbase[n]);
+  hipFree(c->vv); hipFree(c->vi); hipFree(c->ii); hipFree(c->iv); hipFree(c->ecls); hipFree(c->lut); hipFree(c->met);
+  hipFree(c->cpcoef);
+  for (int n = 0; n < 12; ++n) hipFree(c->psi[n]);
+  for (int f = 0; f < 6; ++f) { hipFree(c->mur[f].st[0]); hipFree(c->mur[f].st[1]); }
+  hipFree(c->sig); hipFree(c->src_off); hipFree(c->src_comp); hipFree(c->src_amp); hipFree(c->src_delay);
+  for (int q = 0; q < c->nprobe; ++q) {
+    hipFree((void*)c->probe[q].off); hipFree((void*)c->probe[q].comp); hipFree((void*)c->probe[q].w); hipFree(c->probe[q].series);
+  }
+  for (int b = 0; b < c->nbox; ++b) hipFree(c->box[b].acc);
+  hipFree(c->d_probe); hipFree(c->d_box); hipFree(c->tw_v); hipFree(c->tw_i);
+  hipFree(c->d_step); hipFree(c->d_energy);
+  if (c->ev_E) hipEventDestroy(c->ev_E);
+  if (c->ev_H) hipEventDestroy(c->ev_H);
+  if (c->ev_haloE) hipEventDestroy(c->ev_haloE);
+  if (c->ev_haloH) hipEventDestroy(c->ev_haloH);
+  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->comm_stream) hipStreamDestroy(c->comm_stream);
+  delete c;
+}
+
+
+int fdtd_set_operator_raw(fdtd_ctx* c, const float* vv, const float* vi, const float* ii, const float* iv) {
+  if (!c || !vv || !vi || !ii || !iv) return fdtd_fail(c, FDTD_E_ARG, "null operator array");
+  HIPCK(c, hipSetDevice(c->d.device));
+  const size_t bytes = 3 * c->nloc * sizeof(float);
+  const float* src[4] = {vv, vi, ii, iv};
+  float** dst[4] = {&c->vv, &c->vi, &c->ii, &c->iv};
+  const size_t rows = (size_t)3 * c->d.nk * c->d.ny;
+  for (int n = 0; n < 4; ++n) {
+    if (!*dst[n]) HIPCK(c, hipMalloc(dst[n], bytes));
+    HIPCK(c, hipMemset(*dst[n], 0, bytes));
+    HIPCK(c, upload_rows(*dst[n], c->P, src[n], c->d.nx, rows));
+  }
+  c->p.vv = c->vv; c->p.vi = c->vi; c->p.ii = c->ii; c->p.iv = c->iv;
+  c->have_op = true; c->raw_op = true;
+  return FDTD_OK;
+}
+
+int fdtd_set_operator_classes(fdtd_ctx* c, const uint8_t* ecls, int ncls, const float* cls_vv, const float* cls_m,
+                              const float* emet, const float* hmet) {
+  if (!c || !ecls || !cls_vv || !cls_m || !emet || !hmet || ncls < 1 || ncls > 256)
+    return fdtd_fail(c, FDTD_E_ARG, "bad class operator");
+  HIPCK(c, hipSetDevice(c->d.device));
+  const int nx = c->d.nx, ny = c->d.ny, nk = c->d.nk, P = c->P;
+  const size_t n = 3 * c->nloc;
+  for (size_t q = 0; q < (size_t)3 * nk * ny * nx; ++q)
+    if (ecls[q] >= ncls) return fdtd_fail(c, FDTD_E_ARG, "class %d >= ncls %d", (int)ecls[q], ncls);
+  if (!c->ecls) HIPCK(c, hipMalloc(&c->ecls, n));
+  HIPCK(c, hipMemset(c->ecls, 0, n));
+  HIPCK(c, upload_rows(c->ecls, P, ecls, nx, (size_t)3 * nk * ny));
+  std::vector<float2> lut(256, make_float2(0.f, 0.f));
+  for (int q = 0; q < ncls; ++q) lut[q] = make_float2(cls_vv[q], cls_m[q]);
+  HIPCK(c, hipMemcpy(c->lut, lut.data(), 256 * sizeof(float2), hipMemcpyHostToDevice));
+  // metric tables: per (E|H, comp): x (padded to P, zeros), y, z — each segment 4-float aligned
+  auto al4 = [](int v) { return (v + 3) / 4 * 4; };
+  const int seg = P + al4(ny) + al4(nk);
+  std::vector<float> host((size_t)6 * seg, 0.f);
+  const int tl = nx + ny + nk;
+  for (int eh = 0; eh < 2; ++eh)
+    for (int comp = 0; comp < 3; ++comp) {
+      const float* src = (eh ? hmet : emet) + (size_t)comp * tl;
+      float* dst = host.data() + (size_t)(eh * 3 + comp) * seg;
+      memcpy(dst, src, nx * sizeof(float));
+      memcpy(dst + P, src + nx, ny * sizeof(float));
+      memcpy(dst + P + al4(ny), src + nx + ny, nk * sizeof(float));
+    }
+  if (!c->met) HIPCK(c, hipMalloc(&c->met, host.size() * sizeof(float)));
+  HIPCK(c, hipMemcpy(c->met, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  for (int comp = 0; comp < 3; ++comp) {
+    const float* e = c->met + (size_t)comp * seg;
+    const float* h = c->met + (size_t)(3 + comp) * seg;
+    c->p.emet[comp][0] = e; c->p.emet[comp][1] = e + P; c->p.emet[comp][2] = e + P + al4(ny);
+    c->p.hmet[comp][0] = h; c->p.hmet[comp][1] = h + P; c->p.hmet[comp][2] = h + P + al4(ny);
+  }
+  c->p.ecls = c->ecls; c->p.lut = c->lut;
+  c->have_op = true; c->raw_op = false;
+  return FDTD_OK;
+}
+
+int fdtd_set_cpml(fdtd_ctx* c, const int32_t* sx, const int32_t* sy, const int32_t* sz, int nsx, int nsy, int nsz,
+                  const float* coef) {
+  if (!c || !sx || !sy || !sz || !coef) return fdtd_fail(c, FDTD_E_ARG, "null cpml argument");
+  HIPCK(c, hipSetDevice(c->d.device));
+  const int32_t* s[3] = {sx, sy, sz};
+  const int ns[3] = {nsx, nsy, nsz};
+  // the kernels address psi through two contiguous index ranges per axis: [0,lo) and [hi,n)
+  for (int a = 0; a < 3; ++a) {
+    const int n = n_axis(c, a);
+    int lo = 0;
+    while (lo < n && s[a][lo] == lo) ++lo;
+    int hi = lo;
+    while (hi < n && s[a][hi] < 0) ++hi;
+    for (int q = hi; q < n; ++q)
+      if (s[a][q] != lo + (q - hi)) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "cpml slots on axis %d are not two end-anchored contiguous ranges", a);
+    const int used = lo + (n - hi);
+    if (used != ns[a]) return fdtd_fail(c, FDTD_E_ARG, "cpml axis %d: %d slots declared, %d used", a, ns[a], used);
+    c->p.pml_lo[a] = lo; c->p.pml_hi[a] = hi < n ? hi : (1 << 30); c->p.pml_hi_slot[a] = lo; c->p.nslot[a] = ns[a];
+  }
+  // coefficient tables -> device, x tables padded to P (identity)
+  const int nx = c->d.nx, ny = c->d.ny, nk = c->d.nk, P = c->P;
+  auto al4 = [](int v) { return (v + 3) / 4 * 4; };
+  const int len[3] = {P, al4(ny), al4(nk)};
+  const int nn[3] = {nx, ny, nk};
+  size_t tot = 0;
+  for (int a = 0; a < 3; ++a) tot += (size_t)6 * len[a];
+  std::vector<float> host(tot, 0.f);
+  size_t doff = 0, soff = 0;
+  size_t tab_off[3][2][3];
+  for (int a = 0; a < 3; ++a)
+    for (int eh = 0; eh < 2; ++eh)
+      for (int w = 0; w < 3; ++w) {
+        float* dst = host.data() + doff;
+        for (int q = 0; q < len[a]; ++q) dst[q] = (w == 2) ? 1.f : 0.f;
+        memcpy(dst, coef + soff, nn[a] * sizeof(float));
+        tab_off[a][eh][w] = doff;
+        doff += len[a]; soff += nn[a];
+      }
+  hipFree(c->cpcoef); c->cpcoef = nullptr;
+  HIPCK(c, hipMalloc(&c->cpcoef, tot * sizeof(float)));
+  HIPCK(c, hipMemcpy(c->cpcoef, host.data(), tot * sizeof(float), hipMemcpyHostToDevice));
+  for (int a = 0; a < 3; ++a)
+    for (int eh = 0; eh < 2; ++eh)
+      for (int w = 0; w < 3; ++w) c->p.cp[a][eh][w] = c->cpcoef + tab_off[a][eh][w];
+  // psi: axis x -> [nk][ny][nsx]; y -> [nk][nsy][P]; z -> [nsz][ny][P]
+  const size_t psz[3] = {(size_t)nk * ny * nsx, (size_t)nk * nsy * P, (size_t)nsz * ny * P};
+  for (int n = 0; n < 12; ++n) { hipFree(c->psi[n]); c->psi[n] = nullptr; }
+  for (int eh = 0; eh < 2; ++eh)
+    for (int comp = 0; comp < 3; ++comp)
+      for (int w = 0; w < 2; ++w) {
+        const int a = (comp + 1 + w) % 3;
+        float* ptr = nullptr;
+        // allocate at least 16 B so interior kernels always hold a valid pointer
+        const size_t bytes = std::max<size_t>(psz[a] * sizeof(float), 16);
+        HIPCK(c, hipMalloc(&ptr, bytes));
+        HIPCK(c, hipMemset(ptr, 0, bytes));
+        c->psi[(eh * 3 + comp) * 2 + w] = ptr;
+        (eh ? c->p.psiH : c->p.psiE)[comp][w] = ptr;
+      }
+  c->have_cpml = (nsx + nsy + nsz) > 0;
+  return FDTD_OK;
+}
+
+int fdtd_set_mur(fdtd_ctx* c, const int32_t enable[6], const float coeff[6]) {
+  if (!c || !enable || !coeff) return fdtd_fail(c, FDTD_E_ARG, "null mur argument");
+  HIPCK(c, hipSetDevice(c->d.device));
+  c->any_mur = false;
+  for (int f = 0; f < 6; ++f) {
+    const int a = f / 2;
+    int on = enable[f] != 0;
+    if (a == 2) {
+      const int b = (f & 1) ? c->d.nz - 1 : 0;
+      if (b < c->d.k0 || b >= c->d.k0 + c->d.nk) on = 0;
+      else if (on && c->d.nk < 2) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "Mur z face needs nk >= 2");
+    }
+    const size_t n = a == 0 ? (size_t)c->d.nk * c->d.ny : a == 1 ? (size_t)c->d.nk * c->d.nx : (size_t)c->d.ny * c->d.nx;
+    for (int t = 0; t < 2; ++t) {
+      hipFree(c->mur[f].st[t]); c->mur[f].st[t] = nullptr;
+      if (on) {
+        HIPCK(c, hipMalloc(&c->mur[f].st[t], n * sizeof(float)));
+        HIPCK(c, hipMemset(c->mur[f].st[t], 0, n * sizeof(float)));
+      }
+    }
+    c->mur[f].on = on; c->mur[f].coeff = coeff[f]; c->mur[f].n = (int)n;
+    c->any_mur |= on != 0;
+  }
+  return FDTD_OK;
+}
+
+int fdtd_set_signal(fdtd_ctx* c, const float* sig, int n) {
+  if (!c || !sig || n < 1) return fdtd_fail(c, FDTD_E_ARG, "bad signal");
+  HIPCK(c, hipSetDevice(c->d.device));
+  hipFree(c->sig); c->sig = nullptr;
+  HIPCK(c, hipMalloc(&c->sig, n * sizeof(float)));
+  HIPCK(c, hipMemcpy(c->sig, sig, n * sizeof(float), hipMemcpyHostToDevice));
+  c->nsig = n;
+  return FDTD_OK;
+}
+
+// global flat node index -> padded local offset; -1 not owned, -2 outside the grid
+static long to_local(const fdtd_ctx* c, int64_t g) {
+  const int64_t gplane = (int64_t)c->d.nx * c->d.ny;
+  if (g < 0 || g >= gplane * c->d.nz) return -2;
+  const int64_t k = g / gplane, r = g - k * gplane;
+  if (k < c->d.k0 || k >= c->d.k0 + c->d.nk) return -1;
+  const int64_t j = r / c->d.nx, i = r - j * c->d.nx;
+  return (long)((k - c->d.k0) * c->plane + j * c->P + i);
+}
+
+
+int fdtd_add_source(fdtd_ctx* c, int n, const int64_t* idx, const int8_t* comp, const float* amp, const int32_t* delay) {
+  if (!c || n < 0 || (n && (!idx || !comp || !amp || !delay))) return fdtd_fail(c, FDTD_E_ARG, "bad source");
+  HIPCK(c, hipSetDevice(c->d.device));
+  for (int e = 0; e < n; ++e) {
+    const long l = to_local(c, idx[e]);
+    if (l == -2 || comp[e] < 0 || comp[e] > 2) return fdtd_fail(c, FDTD_E_ARG, "source edge %d out of grid", e);
+    if (l < 0) continue;
+    c->h_src_off.push_back((int)l); c->h_src_comp.push_back(comp[e]);
+    c->h_src_amp.push_back(amp[e]); c->h_src_delay.push_back(delay[e]);
+  }
+  c->nsrc = (int)c->h_src_off.size();
+  HIPCK(c, to_device(&c->src_off, c->h_src_off));
+  HIPCK(c, to_device(&c->src_comp, c->h_src_comp));
+  HIPCK(c, to_device(&c->src_amp, c->h_src_amp));
+  HIPCK(c, to_device(&c->src_delay, c->h_src_delay));
+  return FDTD_OK;
+}
+
+int fdtd_add_probe(fdtd_ctx* c, int kind, int n, const int64_t* idx, const int8_t* comp, const float* w, int* id_out) {
+  if (!c || n < 0 || (n && (!idx || !comp || !w)) || (kind != 0 && kind != 1)) return fdtd_fail(c, FDTD_E_ARG, "bad probe");
+  if (c->nprobe >= FDTD_MAX_PROBES) return fdtd_fail(c, FDTD_E_NOMEM, "too many probes");
+  HIPCK(c, hipSetDevice(c->d.device));
+  std::vector<int> off; std::vector<int8_t> cm; std::vector<float> ww;
+  for (int e = 0; e < n; ++e) {
+    const long l = to_local(c, idx[e]);
+    if (l == -2 || comp[e] < 0 || comp[e] > 2) return fdtd_fail(c, FDTD_E_ARG, "probe edge %d out of grid", e);
+    if (l < 0) continue;
+    off.push_back((int)l); cm.push_back(comp[e]); ww.push_back(w[e]);
+  }
+  DevProbe& p = c->probe[c->nprobe];
+  p = DevProbe{};
+  p.kind = kind; p.n = (int)off.size();
+  int* d_off = nullptr; int8_t* d_cm = nullptr; float* d_w = nullptr;
+  HIPCK(c, to_device(&d_off, off));
+  HIPCK(c, to_device(&d_cm, cm));
+  HIPCK(c, to_device(&d_w, ww));
+  p.off = d_off; p.comp = d_cm; p.w = d_w;
+  const size_t cap = std::max(c->d.max_steps, 1);
+  HIPCK(c, hipMalloc(&p.series, cap * sizeof(double)));
+  HIPCK(c, hipMemset(p.series, 0, cap * sizeof(double)));
+  if (id_out) *id_out = c->nprobe;
+  c->nprobe++;
+  HIPCK(c, hipMemcpy(c->d_probe, c->probe, sizeof(DevProbe) * FDTD_MAX_PROBES, hipMemcpyHostToDevice));
+  return FDTD_OK;
+}
+
+int fdtd_get_probe(fdtd_ctx* c, int id, double* out, int cap, int* n_out) {
+  if (!c || id < 0 || id >= c->nprobe) return fdtd_fail(c, FDTD_E_ARG, "bad probe id");
+  HIPCK(c, hipSetDevice(c->d.device));
+  const int n = (int)std::min<int64_t>(c->step, c->d.max_steps);
+  if (n_out) *n_out = n;
+  const int m = std::min(n, cap);
+  if (out && m > 0) {
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(out, c->probe[id].series, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return FDTD_OK;
+}
+
+int fdtd_set_dft(fdtd_ctx* c, int nfreq, int every, int nsamples, const double* tw_v, const double* tw_i) {
+  if (!c || nfreq < 1 || every < 1 || nsamples < 1 || !tw_v || !tw_i) return fdtd_fail(c, FDTD_E_ARG, "bad dft setup");
+  if (c->nbox) return fdtd_fail(c, FDTD_E_STATE, "set_dft must precede add_dft_box");
+  HIPCK(c, hipSetDevice(c->d.device));
+  const size_t bytes = (size_t)nsamples * nfreq * 2 * sizeof(double);
+  hipFree(c->tw_v); hipFree(c->tw_i); c->tw_v = c->tw_i = nullptr;
+  HIPCK(c, hipMalloc(&c->tw_v, bytes));
+  HIPCK(c, hipMalloc(&c->tw_i, bytes));
+  HIPCK(c, hipMemcpy(c->tw_v, tw_v, bytes, hipMemcpyHostToDevice));
+  HIPCK(c, hipMemcpy(c->tw_i, tw_i, bytes, hipMemcpyHostToDevice));
+  c->nfreq = nfreq; c->every = every; c->nsamples = nsamples;
+  return FDTD_OK;
+}
+
+int fdtd_add_dft_box(fdtd_ctx* c, int kind, int comp, const int32_t lo[3], const int32_t hi[3], int* id_out) {
+  if (!c || !lo || !hi || comp < 0 || comp > 2 || (kind != 0 && kind != 1)) return fdtd_fail(c, FDTD_E_ARG, "bad dft box");
+  if (!c->nfreq) return fdtd_fail(c, FDTD_E_STATE, "set_dft first");
+  if (c->nbox >= FDTD_MAX_BOXES) return fdtd_fail(c, FDTD_E_NOMEM, "too many dft boxes");
+  HIPCK(c, hipSetDevice(c->d.device));
+  const int dims[3] = {c->d.nx, c->d.ny, c->d.nz};
+  for (int a = 0; a < 3; ++a)
+    if (lo[a] < 0 || hi[a] >= dims[a] || hi[a] < lo[a]) return fdtd_fail(c, FDTD_E_ARG, "dft box outside grid");
+  const int b = c->nbox;
+  int32_t olo[3] = {lo[0], lo[1], std::max(lo[2], c->d.k0)};
+  int32_t ohi[3] = {hi[0], hi[1], std::min(hi[2], c->d.k0 + c->d.nk - 1)};
+  for (int a = 0; a < 3; ++a) { c->box_lo[b][a] = olo[a]; c->box_hi[b][a] = ohi[a]; }
+  DevBox& bx = c->box[b];
+  bx = DevBox{};
+  bx.kind = kind; bx.comp = comp;
+  if (ohi[2] >= olo[2]) {
+    bx.lo[0] = olo[0]; bx.lo[1] = olo[1]; bx.lo[2] = olo[2] - c->d.k0;
+    bx.ni = ohi[0] - olo[0] + 1; bx.nj = ohi[1] - olo[1] + 1; bx.nkk = ohi[2] - olo[2] + 1;
+    bx.npts = (long)bx.ni * bx.nj * bx.nkk;
+    const size_t bytes = (size_t)bx.npts * c->nfreq * 2 * sizeof(double);
+    HIPCK(c, hipMalloc(&bx.acc, bytes));
+    HIPCK(c, hipMemset(bx.acc, 0, bytes));
+    c->box_maxpts[kind] = std::max(c->box_maxpts[kind], bx.npts);
+  }
+  if (id_out) *id_out = b;
+  c->nbox++;
+  HIPCK(c, hipMemcpy(c->d_box, c->box, sizeof(DevBox) * FDTD_MAX_BOXES, hipMemcpyHostToDevice));
+  return FDTD_OK;
+}
+
+int fdtd_get_dft_box(fdtd_ctx* c, int id, double* out, int32_t lo_own[3], int32_t hi_own[3]) {
+  if (!c || id < 0 || id >= c->nbox) return fdtd_fail(c, FDTD_E_ARG, "bad dft box id");
+  HIPCK(c, hipSetDevice(c->d.device));
+  for (int a = 0; a < 3; ++a) { if (lo_own) lo_own[a] = c->box_lo[id][a]; if (hi_own) hi_own[a] = c->box_hi[id][a]; }
+  const DevBox& bx = c->box[id];
+  if (out && bx.npts) {
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(out, bx.acc, (size_t)bx.npts * c->nfreq * 2 * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return FDTD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stepping
+// ------------------------------------------------------------------------------------------------
+static int check_ready(fdtd_ctx* c) {
+  if (!c) return FDTD_E_ARG;
+  if (!c->have_op) return fdtd_fail(c, FDTD_E_STATE, "operator not set");
+  return FDTD_OK;
+}
+
+// Halo exchange on the communication stream.  which = FDTD_HALO_E_DOWN: Vx,Vy plane 0 -> rank-1, ghost
+// plane nk <- rank+1.  FDTD_HALO_H_UP: Ix,Iy plane nk-1 -> rank+1, ghost plane -1 <- rank-1.
+static int exchange(fdtd_ctx* c, int which) {
+  ncclComm_t comm = (ncclComm_t)c->comm;
+  const int r = c->d.rank, w = c->d.world;
+  const size_t cnt = (size_t)c->plane;
+  const long top = (long)(c->d.nk - 1) * c->plane;
+  hipEvent_t after = which == FDTD_HALO_E_DOWN ? c->ev_E : c->ev_H;
+  HIPCK(c, hipEventRecord(after, c->stream));
+  HIPCK(c, hipStreamWaitEvent(c->comm_stream, after, 0));
+  NCCLCK(c, ncclGroupStart());
+  if (which == FDTD_HALO_E_DOWN) {
+    if (r > 0) {
+      NCCLCK(c, ncclSend(c->p.V[0], cnt, ncclFloat, r - 1, comm, c->comm_stream));
+      NCCLCK(c, ncclSend(c->p.V[1], cnt, ncclFloat, r - 1, comm, c->comm_stream));
+    }
+    if (r < w - 1) {
+      NCCLCK(c, ncclRecv(c->p.V[0] + c->nloc, cnt, ncclFloat, r + 1, comm, c->comm_stream));
+      NCCLCK(c, ncclRecv(c->p.V[1] + c->nloc, cnt, ncclFloat, r + 1, comm, c->comm_stream));
+    }
+  } else {
+    if (r < w - 1) {
+      NCCLCK(c, ncclSend(c->p.I[0] + top, cnt, ncclFloat, r + 1, comm, c->comm_stream));
+      NCCLCK(c, ncclSend(c->p.I[1] + top, cnt, ncclFloat, r + 1, comm, c->comm_stream));
+    }
+    if (r > 0) {
+      NCCLCK(c, ncclRecv(c->p.I[0] - c->plane, cnt, ncclFloat, r - 1, comm, c->comm_stream));
+      NCCLCK(c, ncclRecv(c->p.I[1] - c->plane, cnt, ncclFloat, r - 1, comm, c->comm_stream));
+    }
+  }
+  NCCLCK(c, ncclGroupEnd());
+  if (which == FDTD_HALO_E_DOWN) { HIPCK(c, hipEventRecord(c->ev_haloE, c->comm_stream)); c->haloE_pending = true; }
+  else { HIPCK(c, hipEventRecord(c->ev_haloH, c->comm_stream)); c->haloH_pending = true; }
+  return FDTD_OK;
+}
+
+struct ProfEvents {
+  std::vector<hipEvent_t> e0, e1, h0, h1;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
+  const int nk = c->d.nk;
+  const bool multi = c->d.world > 1;
+  if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_comm_init (RCCL) or drive fdtd_half_step + fdtd_halo_*");
+  hipStream_t s = c->stream;
+  for (int n = 0; n < nsteps; ++n) {
+    // ---- E half-step: interior planes first, plane 0 (needs the H ghost from below) last ----
+    launch_mur(c, 0, s);
+    if (pe) HIPCK(c, hipEventRecord(pe->e0[n], s));
+    if (multi && c->d.rank > 0) {
+      launch_update_E(c, 1, nk, s);
+      if (pe) HIPCK(c, hipEventRecord(pe->e1[n], s));
+      if (c->haloH_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloH, 0)); c->haloH_pending = false; }
+      launch_update_E(c, 0, 1, s);
+    } else {
+      launch_update_E(c, 0, nk, s);
+      if (pe) HIPCK(c, hipEventRecord(pe->e1[n], s));
+      if (c->haloH_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloH, 0)); c->haloH_pending = false; }
+    }
+    launch_mur(c, 1, s);
+    launch_mur(c, 2, s);
+    launch_post(c, FDTD_KIND_V, s);
+    if (multi) { int r = exchange(c, FDTD_HALO_E_DOWN); if (r) return r; }
+    // ---- H half-step: all planes but the top one overlap the E halo; the top plane goes last ----
+    if (pe) HIPCK(c, hipEventRecord(pe->h0[n], s));
+    if (multi && c->d.rank < c->d.world - 1) {
+      launch_update_H(c, 0, nk - 1, s);
+      if (pe) HIPCK(c, hipEventRecord(pe->h1[n], s));
+      if (c->haloE_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloE, 0)); c->haloE_pending = false; }
+      launch_update_H(c, nk - 1, nk, s);
+    } else {
+      launch_update_H(c, 0, nk, s);
+      if (pe) HIPCK(c, hipEventRecord(pe->h1[n], s));
+      if (c->haloE_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloE, 0)); c->haloE_pending = false; }
+    }
+    launch_post(c, FDTD_KIND_I, s);
+    if (multi) { int r = exchange(c, FDTD_HALO_H_UP); if (r) return r; }
+    c->step++;
+  }
+  HIPCK(c, hipGetLastError());
+  return FDTD_OK;
+}
+
+int fdtd_run(fdtd_ctx* c, int nsteps) {
+  int r = check_ready(c);
+  if (r) return r;
+  HIPCK(c, hipSetDevice(c->d.device));
+  r = step_loop(c, nsteps, nullptr);
+  if (r) return r;
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  HIPCK(c, hipStreamSynchronize(c->comm_stream));
+  return FDTD_OK;
+}
+
+int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
+  int r = check_ready(c);
+  if (r) return r;
+  if (!out || nsteps < 1 || nsteps > 20000) return fdtd_fail(c, FDTD_E_ARG, "profiled run: 1..20000 steps");
+  HIPCK(c, hipSetDevice(c->d.device));
+  ProfEvents pe;
+  auto mk = [&](std::vector<hipEvent_t>& v) { v.resize(nsteps); for (auto& e : v) hipEventCreate(&e); };
+  mk(pe.e0); mk(pe.e1); mk(pe.h0); mk(pe.h1);
+  hipEventCreate(&pe.t0); hipEventCreate(&pe.t1);
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  HIPCK(c, hipEventRecord(pe.t0, c->stream));
+  r = step_loop(c, nsteps, &pe);
+  if (r == FDTD_OK) {
+    hipEventRecord(pe.t1, c->stream);
+    hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->comm_stream);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, pe.t0, pe.t1);
+    memset(out, 0, sizeof(*out));
+    out->ms_total = ms; out->steps = nsteps;
+    double se = 0, sh = 0;
+    for (int n = 0; n < nsteps; ++n) {
+      hipEventElapsedTime(&ms, pe.e0[n], pe.e1[n]); se += ms;
+      hipEventElapsedTime(&ms, pe.h0[n], pe.h1[n]); sh += ms;
+    }
+    out->ms_update_e = se / nsteps; out->ms_update_h = sh / nsteps;
+    out->launches_e = out->launches_h = nsteps;
+  }
+  for (auto* v : {&pe.e0, &pe.e1, &pe.h0, &pe.h1}) for (auto e : *v) hipEventDestroy(e);
+  hipEventDestroy(pe.t0); hipEventDestroy(pe.t1);
+  return r;
+}
+
+int fdtd_get_step(fdtd_ctx* c, int64_t* step) {
+  if (!c || !step) return FDTD_E_ARG;
+  *step = c->step;
+  return FDTD_OK;
+}
+
+int fdtd_energy(fdtd_ctx* c, double sums[2]) {
+  if (!c || !sums) return FDTD_E_ARG;
+  HIPCK(c, hipSetDevice(c->d.device));
+  launch_energy(c, c->stream);
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  HIPCK(c, hipMemcpy(sums, c->d_energy, 2 * sizeof(double), hipMemcpyDeviceToHost));
+  return FDTD_OK;
+}
+
+// ---- external halo transport --------------------------------------------------------------------
+int fdtd_half_step(fdtd_ctx* c, int phase) {
+  int r = check_ready(c);
+  if (r) return r;
+  HIPCK(c, hipSetDevice(c->d.device));
+  hipStream_t s = c->stream;
+  if (phase == FDTD_PHASE_E) {
+    launch_mur(c, 0, s);
+    launch_update_E(c, 0, c->d.nk, s);
+    launch_mur(c, 1, s);
+    launch_mur(c, 2, s);
+    launch_post(c, FDTD_KIND_V, s);
+  } else if (phase == FDTD_PHASE_H) {
+    launch_update_H(c, 0, c->d.nk, s);
+    launch_post(c, FDTD_KIND_I, s);
+    c->step++;
+  } else return fdtd_fail(c, FDTD_E_ARG, "bad phase");
+  HIPCK(c, hipGetLastError());
+  HIPCK(c, hipStreamSynchronize(s));
+  return FDTD_OK;
+}
+
+static hipError_t plane_d2h(const fdtd_ctx* c, float* host, const float* dev) {
+  return hipMemcpy2D(host, (size_t)c->d.nx * 4, dev, (size_t)c->P * 4, (size_t)c->d.nx * 4, c->d.ny, hipMemcpyDeviceToHost);
+}
+static hipError_t plane_h2d(const fdtd_ctx* c, float* dev, const float* host) {
+  return hipMemcpy2D(dev, (size_t)c->P * 4, host, (size_t)c->d.nx * 4, (size_t)c->d.nx * 4, c->d.ny, hipMemcpyHostToDevice);
+}
+
+int fdtd_halo_get(fdtd_ctx* c, int which, float* buf) {
+  if (!c || !buf) return FDTD_E_ARG;
+  HIPCK(c, hipSetDevice(c->d.device));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  const size_t hp = (size_t)c->d.nx * c->d.ny;
+  if (which == FDTD_HALO_H_UP) {
+    const long top = (long)(c->d.nk - 1) * c->plane;
+    HIPCK(c, plane_d2h(c, buf, c->p.I[0] + top));
+    HIPCK(c, plane_d2h(c, buf + hp, c->p.I[1] + top));
+  } else if (which == FDTD_HALO_E_DOWN) {
+    HIPCK(c, plane_d2h(c, buf, c->p.V[0]));
+    HIPCK(c, plane_d2h(c, buf + hp, c->p.V[1]));
+  } else return fdtd_fail(c, FDTD_E_ARG, "bad halo id");
+  return FDTD_OK;
+}
+
+int fdtd_halo_put(fdtd_ctx* c, int which, const float* buf) {
+  if (!c || !buf) return FDTD_E_ARG;
+  HIPCK(c, hipSetDevice(c->d.device));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  const size_t hp = (size_t)c->d.nx * c->d.ny;
+  if (which == FDTD_HALO_H_UP) {
+    HIPCK(c, plane_h2d(c, c->p.I[0] - c->plane, buf));
+    HIPCK(c, plane_h2d(c, c->p.I[1] - c->plane, buf + hp));
+  } else if (which == FDTD_HALO_E_DOWN) {
+    HIPCK(c, plane_h2d(c, c->p.V[0] + c->nloc, buf));
+    HIPCK(c, plane_h2d(c, c->p.V[1] + c->nloc, buf + hp));
+  } else return fdtd_fail(c, FDTD_E_ARG, "bad halo id");
+  return FDTD_OK;
+}
+
+// ---- RCCL transport -----------------------------------------------------------------------------
+int fdtd_comm_unique_id(void* out128) {
+  if (!out128) return fdtd_fail(nullptr, FDTD_E_ARG, "null id buffer");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  NCCLCK(nullptr, ncclGetUniqueId(&id));
+  memcpy(out128, &id, 128);
+  return FDTD_OK;
+}
+
+int fdtd_comm_init(fdtd_ctx* c, const void* uid128) {
+  if (!c || !uid128) return fdtd_fail(c, FDTD_E_ARG, "null argument");
+  if (c->comm) return fdtd_fail(c, FDTD_E_STATE, "communicator already initialised");
+  HIPCK(c, hipSetDevice(c->d.device));
+  ncclUniqueId id;
+  memcpy(&id, uid128, 128);
+  ncclComm_t comm;
+  NCCLCK(c, ncclCommInitRank(&comm, c->d.world, id, c->d.rank));
+  c->comm = comm;
+  return FDTD_OK;
+}
+
+// ---- field access -------------------------------------------------------------------------------
+int fdtd_get_field(fdtd_ctx* c, int kind, int comp, float* out) {
+  if (!c || !out || comp < 0 || comp > 2 || (kind != 0 && kind != 1)) return fdtd_fail(c, FDTD_E_ARG, "bad field id");
+  HIPCK(c, hipSetDevice(c->d.device));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  const float* src = kind == FDTD_KIND_V ? c->p.V[comp] : c->p.I[comp];
+  HIPCK(c, hipMemcpy2D(out, (size_t)c->d.nx * 4, src, (size_t)c->P * 4, (size_t)c->d.nx * 4, (size_t)c->d.nk * c->d.ny,
+                       hipMemcpyDeviceToHost));
+  return FDTD_OK;
+}
+
+int fdtd_set_field(fdtd_ctx* c, int kind, int comp, const float* in) {
+  if (!c || !in || comp < 0 || comp > 2 || (kind != 0 && kind != 1)) return fdtd_fail(c, FDTD_E_ARG, "bad field id");
+  HIPCK(c, hipSetDevice(c->d.device));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  float* dst = kind == FDTD_KIND_V ? c->p.V[comp] : c->p.I[comp];
+  HIPCK(c, hipMemcpy2D(dst, (size_t)c->P * 4, in, (size_t)c->d.nx * 4, (size_t)c->d.nx * 4, (size_t)c->d.nk * c->d.ny,
+                       hipMemcpyHostToDevice));
+  return FDTD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// fdtd_ctx.h — host context + device parameter block of libfdtd_hip.so (gfx950 only).
+//
+// HBM layout: every field component is one dense array of (nk+2) z-planes
+// (one ghost plane below and above the owned slab), plane = ny rows of P floats, P = nx rounded
+// up to 4 so every row starts 16-B aligned and a thread's four x-cells are one dwordx4.
+// Rows follow each other without gaps, so a wave reads 1 KiB of consecutive memory whatever nx is.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/fdtd_hip.h"
+
+#define FDTD_MAX_PROBES 64
+#define FDTD_MAX_BOXES 64
+#define FDTD_BLOCK 256
+
+struct DevParams {
+  int nx, ny, nk, P, P4;
+  int plane;  // ny * P (floats)
+  int nloc;   // nk * plane
+  float* V[3];
+  float* I[3];
+  // operator: raw arrays [3][nk*plane] or class bytes + LUT + 1-D metric tables
+  const float* vv; const float* vi; const float* ii; const float* iv;
+  const uint8_t* ecls;
+  const float2* lut;         // [256] (vv, m)
+  const float* emet[3][3];   // [comp][axis], x tables padded to P with zeros
+  const float* hmet[3][3];
+  // CPML: index q along axis a is in a layer iff q < pml_lo[a] (slot q) or q >= pml_hi[a]
+  // (slot q - pml_hi[a] + pml_hi_slot[a]); pml_hi[a] >= n_a disables the upper layer.
+  int pml_lo[3], pml_hi[3], pml_hi_slot[3], nslot[3];
+  const float* cp[3][2][3];  // [axis][E-loc/H-loc][b, c, 1/kappa]
+  float* psiE[3][2];
+  float* psiH[3][2];
+  // launch tiling: a block = 256 threads = 1024 consecutive x-cells of one strip of `tys` rows in one plane
+  int tys, nbs, nstrips;
+};
+
+struct DevProbe { int kind, n; const int* off; const int8_t* comp; const float* w; double* series; };
+struct DevBox   { int kind, comp; int lo[3]; int ni, nj, nkk; double* acc; long npts; };
+
+struct MurFace { int on; float coeff; float* st[2]; int n; };
+
+struct fdtd_ctx {
+  fdtd_desc d{};
+  DevParams p{};
+  int P = 0, plane = 0;
+  size_t nloc = 0;               // nk*plane
+  float* fieldbase[6] = {};      // allocations incl. ghosts
+  float *vv = nullptr, *vi = nullptr, *ii = nullptr, *iv = nullptr;
+  uint8_t* ecls = nullptr;
+  float2* lut = nullptr;
+  float* met = nullptr;          // packed metric tables
+  bool have_op = false, raw_op = false;
+  // cpml
+  bool have_cpml = false;
+  float* cpcoef = nullptr;
+  float* psi[12] = {};
+  // mur
+  MurFace mur[6] = {};
+  bool any_mur = false;
+  // excitation
+  float* sig = nullptr; int nsig = 0;
+  int nsrc = 0; int* src_off = nullptr; int8_t* src_comp = nullptr; float* src_amp = nullptr; int* src_delay = nullptr;
+  std::vector<int> h_src_off; std::vector<int8_t> h_src_comp; std::vector<float> h_src_amp; std::vector<int> h_src_delay;
+  // probes
+  int nprobe = 0; DevProbe probe[FDTD_MAX_PROBES] = {}; DevProbe* d_probe = nullptr;
+  // dft
+  int nfreq = 0, every = 0, nsamples = 0; double *tw_v = nullptr, *tw_i = nullptr;
+  int nbox = 0; DevBox box[FDTD_MAX_BOXES] = {}; DevBox* d_box = nullptr;
+  int32_t box_lo[FDTD_MAX_BOXES][3] = {}, box_hi[FDTD_MAX_BOXES][3] = {};
+  long box_maxpts[2] = {0, 0};
+  // stepping
+  long long* d_step = nullptr;   // device step counter (kernels index signal/probes with it)
+  int64_t step = 0;
+  double* d_energy = nullptr;
+  hipStream_t stream = nullptr, comm_stream = nullptr;
+  hipEvent_t ev_E = nullptr, ev_H = nullptr, ev_haloE = nullptr, ev_haloH = nullptr;
+  bool haloE_pending = false, haloH_pending = false;
+  void* comm = nullptr;          // ncclComm_t
+  bool tables_dirty = true;
+  std::string err;
+};
+
+int fdtd_fail(fdtd_ctx* c, int code, const char* fmt, ...);
+#define HIPCK(c, expr)                                                                       \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fdtd_fail(c, FDTD_E_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// kernels.hip
+void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, hipStream_t s);
+void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, hipStream_t s);
+void launch_mur(fdtd_ctx* c, int mode, hipStream_t s);
+void launch_post(fdtd_ctx* c, int kind, hipStream_t s);   // sources (E) + probes + dft + step++ (H)
+void launch_energy(fdtd_ctx* c, hipStream_t s);
+void choose_tiling(fdtd_ctx* c);

@@ -1,0 +1,473 @@
+// kernels.hip — hand-written gfx950 kernels of the EC-FDTD hot path.
+//
+//   K1 k_update_E   V <- vv*V + vi*curl(I)   + fused CPML psi update      
+//   K2 k_update_H   I <- ii*I + iv*curl(V)   + fused CPML psi update      (N2, N7)
+//   K3 k_post       soft source injection, V/I probe sampling, step++     (N4, N8)
+//   K4 k_mur        first-order Mur pre / post / apply on the six faces   (N6)
+//   K6 k_dft        running DFT of field boxes (NF2FF surfaces)           (N9)
+//   K8 k_energy     sum V^2, sum I^2                                      (N11)
+//
+// These replace what the reference runs inside FDTD.Run(...) of the external openEMS engine
+// (antenna_sim/solver_fdtd_openems_fixed.py:280 and the four sibling call sites).
+//
+// Roofline: 6-point-neighbour stencil, ~0.5 flop/B -> HBM bound, no MFMA.  Algorithmic traffic
+// is 36 B per cell per half-step (read 3+3 fields, write 3).  Design rules applied:
+//   * one thread = 4 consecutive x-cells = one dwordx4 per field component; consecutive lanes
+//     read consecutive memory (rows are stored gap-free), so every wave access is 1 KiB coalesced;
+//   * operator coefficients are NOT streamed: one class byte per edge (3 B/cell) indexes a
+//     256-entry (vv, m) table staged in LDS, the mesh metric comes from 1-D tables in L1;
+//   * blockIdx is remapped so that each XCD (own 4 MiB L2) sweeps one contiguous part of the slab,
+//     ordered strip-by-strip through z so the k+-1 and j+-1 neighbour rows are L2 hits;
+//   * CPML psi arrays exist only inside the layers; interior threads pay three compares.
+//
+// Float32 operation order is pinned with explicit fmaf (compiled with -ffp-contract=off) and is
+// identical to oracle/fdtd_oracle.c, so results are compared bit for bit.
+#include "fdtd_ctx.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 sub4(const float4& a, const float4& b) {
+  return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+
+// XCD-aware, strip-major block decode.  Returns false for threads beyond the strip.
+__device__ __forceinline__ bool decode(const DevParams& p, int k_begin, int nkr, int& k, int& j, int& i0) {
+  const unsigned nb = gridDim.x, b = blockIdx.x;
+  const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
+  const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  const unsigned per_strip = (unsigned)nkr * (unsigned)p.nbs;
+  const unsigned s = v / per_strip;
+  const unsigned rem = v - s * per_strip;
+  const unsigned kk = rem / (unsigned)p.nbs;
+  const unsigned pb = rem - kk * (unsigned)p.nbs;
+  k = k_begin + (int)kk;
+  const int t = (int)pb * FDTD_BLOCK + (int)threadIdx.x;
+  const int rows = min(p.tys, p.ny - (int)s * p.tys);
+  if (t >= rows * p.P4) return false;
+  const int jj = t / p.P4;
+  j = (int)s * p.tys + jj;
+  i0 = (t - jj * p.P4) * 4;
+  return true;
+}
+
+__device__ __forceinline__ int pml_slot(const DevParams& p, int a, int q) {
+  return q < p.pml_lo[a] ? q : (q >= p.pml_hi[a] ? q - p.pml_hi[a] + p.pml_hi_slot[a] : -1);
+}
+
+// psi <- b*psi + c*d ; d <- d/kappa + psi   for the four cells of a thread (row-uniform coefficients)
+__device__ __forceinline__ void cpml_row4(float4& d, float* psi, float b, float c, float ik) {
+  float4 ps = ld4(psi);
+  ps.x = __builtin_fmaf(b, ps.x, c * d.x);
+  ps.y = __builtin_fmaf(b, ps.y, c * d.y);
+  ps.z = __builtin_fmaf(b, ps.z, c * d.z);
+  ps.w = __builtin_fmaf(b, ps.w, c * d.w);
+  st4(psi, ps);
+  d.x = __builtin_fmaf(ik, d.x, ps.x);
+  d.y = __builtin_fmaf(ik, d.y, ps.y);
+  d.z = __builtin_fmaf(ik, d.z, ps.z);
+  d.w = __builtin_fmaf(ik, d.w, ps.w);
+}
+
+// x-directed layers: per-cell coefficients, psi stored [k][j][nslot_x]
+__device__ __forceinline__ void cpml_x4(const DevParams& p, int eh, int i0, int rowslot, float4& da, float* psia,
+                                        float4& db, float* psib) {
+  float a[4] = {da.x, da.y, da.z, da.w};
+  float bb[4] = {db.x, db.y, db.z, db.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = i0 + e;
+    const int sx = pml_slot(p, 0, i);
+    if (sx >= 0 && i < p.nx) {
+      const float b = p.cp[0][eh][0][i], c = p.cp[0][eh][1][i], ik = p.cp[0][eh][2][i];
+      const int o = rowslot + sx;
+      float ps = __builtin_fmaf(b, psia[o], c * a[e]);
+      psia[o] = ps;
+      a[e] = __builtin_fmaf(ik, a[e], ps);
+      ps = __builtin_fmaf(b, psib[o], c * bb[e]);
+      psib[o] = ps;
+      bb[e] = __builtin_fmaf(ik, bb[e], ps);
+    }
+  }
+  da = make_float4(a[0], a[1], a[2], a[3]);
+  db = make_float4(bb[0], bb[1], bb[2], bb[3]);
+}
+
+__device__ __forceinline__ float4 upd4(const float4& ca, const float4& f, const float4& cb, const float4& d1,
+                                       const float4& d2) {
+  return make_float4(__builtin_fmaf(ca.x, f.x, cb.x * (d1.x - d2.x)), __builtin_fmaf(ca.y, f.y, cb.y * (d1.y - d2.y)),
+                     __builtin_fmaf(ca.z, f.z, cb.z * (d1.z - d2.z)), __builtin_fmaf(ca.w, f.w, cb.w * (d1.w - d2.w)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: E half-step
+// ------------------------------------------------------------------------------------------------
+template <bool RAW, bool PML>
+__global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, const int k_begin, const int nkr) {
+  __shared__ float2 s_lut[256];
+  if (!RAW) {
+    s_lut[threadIdx.x] = p.lut[threadIdx.x];
+    __syncthreads();
+  }
+  int k, j, i0;
+  if (!decode(p, k_begin, nkr, k, j, i0)) return;
+  const int off = k * p.plane + j * p.P + i0;
+
+  const float4 ix = ld4(p.I[0] + off), iy = ld4(p.I[1] + off), iz = ld4(p.I[2] + off);
+  const float4 iz_jm = ld4(p.I[2] + off - p.P), ix_jm = ld4(p.I[0] + off - p.P);
+  const float4 iy_km = ld4(p.I[1] + off - p.plane), ix_km = ld4(p.I[0] + off - p.plane);
+  const float iz_im = p.I[2][off - 1], iy_im = p.I[1][off - 1];
+  float4 vx = ld4(p.V[0] + off), vy = ld4(p.V[1] + off), vz = ld4(p.V[2] + off);
+
+  // component x: d1 along y (of Iz), d2 along z (of Iy); y: d1 along z (Ix), d2 along x (Iz);
+  // z: d1 along x (Iy), d2 along y (Ix)
+  float4 dx1 = sub4(iz, iz_jm), dx2 = sub4(iy, iy_km);
+  float4 dy1 = sub4(ix, ix_km);
+  float4 dy2 = make_float4(iz.x - iz_im, iz.y - iz.x, iz.z - iz.y, iz.w - iz.z);
+  float4 dz1 = make_float4(iy.x - iy_im, iy.y - iy.x, iy.z - iy.y, iy.w - iy.z);
+  float4 dz2 = sub4(ix, ix_jm);
+
+  if (PML) {
+    const int sy = pml_slot(p, 1, j);
+    if (sy >= 0) {
+      const float b = p.cp[1][0][0][j], c = p.cp[1][0][1][j], ik = p.cp[1][0][2][j];
+      const int o = (k * p.nslot[1] + sy) * p.P + i0;
+      cpml_row4(dx1, p.psiE[0][0] + o, b, c, ik);
+      cpml_row4(dz2, p.psiE[2][1] + o, b, c, ik);
+    }
+    const int sz = pml_slot(p, 2, k);
+    if (sz >= 0) {
+      const float b = p.cp[2][0][0][k], c = p.cp[2][0][1][k], ik = p.cp[2][0][2][k];
+      const int o = (sz * p.ny + j) * p.P + i0;
+      cpml_row4(dx2, p.psiE[0][1] + o, b, c, ik);
+      cpml_row4(dy1, p.psiE[1][0] + o, b, c, ik);
+    }
+    if (i0 < p.pml_lo[0] || i0 + 3 >= p.pml_hi[0])
+      cpml_x4(p, 0, i0, (k * p.ny + j) * p.nslot[0], dy2, p.psiE[1][1], dz1, p.psiE[2][0]);
+  }
+
+  float4 ax, bx, ay, by, az, bz;
+  if (RAW) {
+    ax = ld4(p.vv + off); bx = ld4(p.vi + off);
+    ay = ld4(p.vv + p.nloc + off); by = ld4(p.vi + p.nloc + off);
+    az = ld4(p.vv + 2 * p.nloc + off); bz = ld4(p.vi + 2 * p.nloc + off);
+  } else {
+    const uchar4 cx = *reinterpret_cast<const uchar4*>(p.ecls + off);
+    const uchar4 cy = *reinterpret_cast<const uchar4*>(p.ecls + p.nloc + off);
+    const uchar4 cz = *reinterpret_cast<const uchar4*>(p.ecls + 2 * p.nloc + off);
+    const float4 ex0 = ld4(p.emet[0][0] + i0), ex1 = ld4(p.emet[1][0] + i0), ex2 = ld4(p.emet[2][0] + i0);
+    const float m0 = p.emet[0][1][j] * p.emet[0][2][k];
+    const float m1 = p.emet[1][1][j] * p.emet[1][2][k];
+    const float m2 = p.emet[2][1][j] * p.emet[2][2][k];
+    float2 l0 = s_lut[cx.x], l1 = s_lut[cx.y], l2 = s_lut[cx.z], l3 = s_lut[cx.w];
+    ax = make_float4(l0.x, l1.x, l2.x, l3.x);
+    bx = make_float4(l0.y * (ex0.x * m0), l1.y * (ex0.y * m0), l2.y * (ex0.z * m0), l3.y * (ex0.w * m0));
+    l0 = s_lut[cy.x]; l1 = s_lut[cy.y]; l2 = s_lut[cy.z]; l3 = s_lut[cy.w];
+    ay = make_float4(l0.x, l1.x, l2.x, l3.x);
+    by = make_float4(l0.y * (ex1.x * m1), l1.y * (ex1.y * m1), l2.y * (ex1.z * m1), l3.y * (ex1.w * m1));
+    l0 = s_lut[cz.x]; l1 = s_lut[cz.y]; l2 = s_lut[cz.z]; l3 = s_lut[cz.w];
+    az = make_float4(l0.x, l1.x, l2.x, l3.x);
+    bz = make_float4(l0.y * (ex2.x * m2), l1.y * (ex2.y * m2), l2.y * (ex2.z * m2), l3.y * (ex2.w * m2));
+  }
+  vx = upd4(ax, vx, bx, dx1, dx2);
+  vy = upd4(ay, vy, by, dy1, dy2);
+  vz = upd4(az, vz, bz, dz1, dz2);
+  st4(p.V[0] + off, vx);
+  st4(p.V[1] + off, vy);
+  st4(p.V[2] + off, vz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: H half-step
+// ------------------------------------------------------------------------------------------------
+template <bool RAW, bool PML>
+__global__ __launch_bounds__(FDTD_BLOCK) void k_update_H(const DevParams p, const int k_begin, const int nkr) {
+  int k, j, i0;
+  if (!decode(p, k_begin, nkr, k, j, i0)) return;
+  const int off = k * p.plane + j * p.P + i0;
+
+  const float4 vx = ld4(p.V[0] + off), vy = ld4(p.V[1] + off), vz = ld4(p.V[2] + off);
+  const float4 vz_jp = ld4(p.V[2] + off + p.P), vx_jp = ld4(p.V[0] + off + p.P);
+  const float4 vy_kp = ld4(p.V[1] + off + p.plane), vx_kp = ld4(p.V[0] + off + p.plane);
+  const float vz_ip = p.V[2][off + 4], vy_ip = p.V[1][off + 4];
+  float4 ix = ld4(p.I[0] + off), iy = ld4(p.I[1] + off), iz = ld4(p.I[2] + off);
+
+  float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);
+  float4 dy1 = sub4(vx, vx_kp);
+  float4 dy2 = make_float4(vz.x - vz.y, vz.y - vz.z, vz.z - vz.w, vz.w - vz_ip);
+  float4 dz1 = make_float4(vy.x - vy.y, vy.y - vy.z, vy.z - vy.w, vy.w - vy_ip);
+  float4 dz2 = sub4(vx, vx_jp);
+
+  if (PML) {
+    const int sy = pml_slot(p, 1, j);
+    if (sy >= 0) {
+      const float b = p.cp[1][1][0][j], c = p.cp[1][1][1][j], ik = p.cp[1][1][2][j];
+      const int o = (k * p.nslot[1] + sy) * p.P + i0;
+      cpml_row4(dx1, p.psiH[0][0] + o, b, c, ik);
+      cpml_row4(dz2, p.psiH[2][1] + o, b, c, ik);
+    }
+    const int sz = pml_slot(p, 2, k);
+    if (sz >= 0) {
+      const float b = p.cp[2][1][0][k], c = p.cp[2][1][1][k], ik = p.cp[2][1][2][k];
+      const int o = (sz * p.ny + j) * p.P + i0;
+      cpml_row4(dx2, p.psiH[0][1] + o, b, c, ik);
+      cpml_row4(dy1, p.psiH[1][0] + o, b, c, ik);
+    }
+    if (i0 < p.pml_lo[0] || i0 + 3 >= p.pml_hi[0])
+      cpml_x4(p, 1, i0, (k * p.ny + j) * p.nslot[0], dy2, p.psiH[1][1], dz1, p.psiH[2][0]);
+  }
+
+  if (RAW) {
+    const float4 ax = ld4(p.ii + off), bx = ld4(p.iv + off);
+    const float4 ay = ld4(p.ii + p.nloc + off), by = ld4(p.iv + p.nloc + off);
+    const float4 az = ld4(p.ii + 2 * p.nloc + off), bz = ld4(p.iv + 2 * p.nloc + off);
+    ix = upd4(ax, ix, bx, dx1, dx2);
+    iy = upd4(ay, iy, by, dy1, dy2);
+    iz = upd4(az, iz, bz, dz1, dz2);
+  } else {
+    // ii = 1: fmaf(1, I, t) == I + t exactly
+    const float4 hx0 = ld4(p.hmet[0][0] + i0), hx1 = ld4(p.hmet[1][0] + i0), hx2 = ld4(p.hmet[2][0] + i0);
+    const float m0 = p.hmet[0][1][j] * p.hmet[0][2][k];
+    const float m1 = p.hmet[1][1][j] * p.hmet[1][2][k];
+    const float m2 = p.hmet[2][1][j] * p.hmet[2][2][k];
+    ix = make_float4(ix.x + (hx0.x * m0) * (dx1.x - dx2.x), ix.y + (hx0.y * m0) * (dx1.y - dx2.y),
+                     ix.z + (hx0.z * m0) * (dx1.z - dx2.z), ix.w + (hx0.w * m0) * (dx1.w - dx2.w));
+    iy = make_float4(iy.x + (hx1.x * m1) * (dy1.x - dy2.x), iy.y + (hx1.y * m1) * (dy1.y - dy2.y),
+                     iy.z + (hx1.z * m1) * (dy1.z - dy2.z), iy.w + (hx1.w * m1) * (dy1.w - dy2.w));
+    iz = make_float4(iz.x + (hx2.x * m2) * (dz1.x - dz2.x), iz.y + (hx2.y * m2) * (dz1.y - dz2.y),
+                     iz.z + (hx2.z * m2) * (dz1.z - dz2.z), iz.w + (hx2.w * m2) * (dz1.w - dz2.w));
+  }
+  st4(p.I[0] + off, ix);
+  st4(p.I[1] + off, iy);
+  st4(p.I[2] + off, iz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: Mur.  One thread per face point and tangential component; blockIdx.y = face*2 + t.
+// ------------------------------------------------------------------------------------------------
+struct MurDevFace {
+  int on, a, b, in;      // axis, local boundary index, inner index
+  int ua, va, du, dv;    // in-face axes (u fast), extents
+  float coeff;
+  float* st[2];
+  int comp[2];
+};
+struct MurDev { MurDevFace f[6]; int bnd[6]; /* local boundary index per face, for the priority rule */ };
+
+__global__ __launch_bounds__(FDTD_BLOCK) void k_mur(const DevParams p, const MurDev m, const int mode) {
+  const int fi = blockIdx.y >> 1, t = blockIdx.y & 1;
+  const MurDevFace& f = m.f[fi];
+  if (!f.on) return;
+  const int s = blockIdx.x * FDTD_BLOCK + threadIdx.x;
+  if (s >= f.du * f.dv) return;
+  const int iv = s / f.du, iu = s - iv * f.du;
+  const int stride[3] = {1, p.P, p.plane};
+  int pos[3];
+  pos[f.a] = f.b; pos[f.ua] = iu; pos[f.va] = iv;
+  const int comp = f.comp[t];
+  float* V = p.V[comp];
+  const int ob = pos[0] + pos[1] * p.P + pos[2] * p.plane;
+  const int oi = ob + (f.in - f.b) * stride[f.a];
+  float* S = f.st[t];
+  if (mode == 0) {
+    S[s] = __builtin_fmaf(-f.coeff, V[ob], V[oi]);
+  } else if (mode == 1) {
+    S[s] = __builtin_fmaf(f.coeff, V[oi], S[s]);
+  } else {
+    // faces are applied in order 0..5 by the reference order; a later face wins on shared edges
+    for (int g = fi + 1; g < 6; ++g) {
+      if (!m.f[g].on) continue;
+      const int ga = g >> 1;
+      if (ga != comp && pos[ga] == m.bnd[g]) return;
+    }
+    V[ob] = S[s];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: sources + probes (+ step++ after the H half-step).  Single block.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FDTD_BLOCK) void k_post(const DevParams p, const int kind, const int nsrc,
+                                                     const int* __restrict__ src_off, const int8_t* __restrict__ src_comp,
+                                                     const float* __restrict__ src_amp, const int* __restrict__ src_delay,
+                                                     const float* __restrict__ sig, const int nsig, const int nprobe,
+                                                     const DevProbe* __restrict__ probes, long long* d_step,
+                                                     const int max_steps) {
+  __shared__ double red[FDTD_BLOCK];
+  const long long step = *d_step;
+  if (kind == FDTD_KIND_V) {
+    for (int e = threadIdx.x; e < nsrc; e += FDTD_BLOCK) {
+      const long long t = step - src_delay[e];
+      if (t >= 0 && t < nsig) {
+        float* v = p.V[src_comp[e]] + src_off[e];
+        *v = *v + src_amp[e] * sig[t];
+      }
+    }
+    __syncthreads();  // single block: sources land before the probes read
+    __threadfence_block();
+  }
+  if (step < max_steps) {
+    for (int q = 0; q < nprobe; ++q) {
+      const DevProbe pr = probes[q];
+      if (pr.kind != kind) continue;
+      double s = 0.0;
+      for (int e = threadIdx.x; e < pr.n; e += FDTD_BLOCK) {
+        const float* F = (kind == FDTD_KIND_V ? p.V[pr.comp[e]] : p.I[pr.comp[e]]);
+        s = fma((double)pr.w[e], (double)F[pr.off[e]], s);
+      }
+      red[threadIdx.x] = s;
+      __syncthreads();
+      for (int w = FDTD_BLOCK / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) pr.series[step] = red[0];
+      __syncthreads();
+    }
+  }
+  if (kind == FDTD_KIND_I && threadIdx.x == 0) *d_step = step + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: running DFT over registered boxes.  blockIdx.y = box, grid-stride over its points.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FDTD_BLOCK) void k_dft(const DevParams p, const int kind, const DevBox* __restrict__ boxes,
+                                                    const int nfreq, const int every, const int nsamples,
+                                                    const double* __restrict__ tw, const long long* d_step) {
+  const long long step = *d_step;
+  if (step % every != 0) return;
+  const long long smp = step / every;
+  if (smp >= nsamples) return;
+  const DevBox bx = boxes[blockIdx.y];
+  if (bx.kind != kind || bx.npts == 0) return;
+  const float* F = (kind == FDTD_KIND_V ? p.V[bx.comp] : p.I[bx.comp]);
+  const double* w = tw + smp * nfreq * 2;
+  for (long pt = (long)blockIdx.x * FDTD_BLOCK + threadIdx.x; pt < bx.npts; pt += (long)gridDim.x * FDTD_BLOCK) {
+    const int ii = (int)(pt % bx.ni);
+    const long r = pt / bx.ni;
+    const int jj = (int)(r % bx.nj), kk = (int)(r / bx.nj);
+    const double v = (double)F[(bx.lo[2] + kk) * p.plane + (bx.lo[1] + jj) * p.P + bx.lo[0] + ii];
+    for (int f = 0; f < nfreq; ++f) {
+      double* a = bx.acc + ((long)f * bx.npts + pt) * 2;
+      a[0] = fma(v, w[2 * f], a[0]);
+      a[1] = fma(v, w[2 * f + 1], a[1]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: energy sums over the owned planes (pads are zero, ghosts excluded).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FDTD_BLOCK) void k_energy(const DevParams p, double* out) {
+  __shared__ double rv[FDTD_BLOCK], ri[FDTD_BLOCK];
+  double sv = 0.0, si = 0.0;
+  const int n4 = p.nloc / 4;
+  for (int t = blockIdx.x * FDTD_BLOCK + threadIdx.x; t < n4; t += gridDim.x * FDTD_BLOCK) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float4 v = ld4(p.V[c] + 4 * t), i = ld4(p.I[c] + 4 * t);
+      sv += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+      si += (double)i.x * i.x + (double)i.y * i.y + (double)i.z * i.z + (double)i.w * i.w;
+    }
+  }
+  rv[threadIdx.x] = sv; ri[threadIdx.x] = si;
+  __syncthreads();
+  for (int w = FDTD_BLOCK / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { rv[threadIdx.x] += rv[threadIdx.x + w]; ri[threadIdx.x] += ri[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { atomicAdd(out, rv[0]); atomicAdd(out + 1, ri[0]); }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+void choose_tiling(fdtd_ctx* c) {
+  // rows per strip: minimise idle lanes in the last block of a strip-plane, prefer ~16 rows
+  const int P4 = c->p.P4, ny = c->p.ny;
+  int best = 1; double best_cost = 1e30;
+  for (int tys = 4; tys <= 40; ++tys) {
+    const int t = (tys < ny ? tys : ny) * P4;
+    const int nbs = (t + FDTD_BLOCK - 1) / FDTD_BLOCK;
+    const double idle = (double)(nbs * FDTD_BLOCK - t) / (nbs * FDTD_BLOCK);
+    const double halo = 1.0 / tys * 0.15;   // j-neighbour rows re-read at strip seams (L2-served)
+    const double cost = idle + halo;
+    if (cost < best_cost - 1e-12) { best_cost = cost; best = tys < ny ? tys : ny; }
+  }
+  c->p.tys = best;
+  c->p.nbs = (best * P4 + FDTD_BLOCK - 1) / FDTD_BLOCK;
+  c->p.nstrips = (ny + best - 1) / best;
+}
+
+void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, hipStream_t s) {
+  const int nkr = k_end - k_begin;
+  if (nkr <= 0) return;
+  const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs)), block(FDTD_BLOCK);
+  if (c->raw_op) {
+    if (c->have_cpml) hipLaunchKernelGGL((k_update_E<true, true>), grid, block, 0, s, c->p, k_begin, nkr);
+    else hipLaunchKernelGGL((k_update_E<true, false>), grid, block, 0, s, c->p, k_begin, nkr);
+  } else {
+    if (c->have_cpml) hipLaunchKernelGGL((k_update_E<false, true>), grid, block, 0, s, c->p, k_begin, nkr);
+    else hipLaunchKernelGGL((k_update_E<false, false>), grid, block, 0, s, c->p, k_begin, nkr);
+  }
+}
+
+void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, hipStream_t s) {
+  const int nkr = k_end - k_begin;
+  if (nkr <= 0) return;
+  const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs)), block(FDTD_BLOCK);
+  if (c->raw_op) {
+    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<true, true>), grid, block, 0, s, c->p, k_begin, nkr);
+    else hipLaunchKernelGGL((k_update_H<true, false>), grid, block, 0, s, c->p, k_begin, nkr);
+  } else {
+    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<false, true>), grid, block, 0, s, c->p, k_begin, nkr);
+    else hipLaunchKernelGGL((k_update_H<false, false>), grid, block, 0, s, c->p, k_begin, nkr);
+  }
+}
+
+void launch_mur(fdtd_ctx* c, int mode, hipStream_t s) {
+  if (!c->any_mur) return;
+  MurDev m{};
+  const int dim[3] = {c->p.nx, c->p.ny, c->p.nk};
+  int maxpts = 1;
+  for (int f = 0; f < 6; ++f) {
+    const int a = f / 2, hi = f & 1;
+    MurDevFace& d = m.f[f];
+    d.on = c->mur[f].on;
+    d.a = a;
+    if (a == 2) d.b = hi ? c->d.nz - 1 - c->d.k0 : -c->d.k0;
+    else d.b = hi ? dim[a] - 1 : 0;
+    d.in = hi ? d.b - 1 : d.b + 1;
+    m.bnd[f] = d.b;
+    const int pa = (a + 1) % 3, qa = (a + 2) % 3;
+    d.ua = pa < qa ? pa : qa;
+    d.va = pa < qa ? qa : pa;
+    d.du = dim[d.ua]; d.dv = dim[d.va];
+    d.coeff = c->mur[f].coeff;
+    d.st[0] = c->mur[f].st[0]; d.st[1] = c->mur[f].st[1];
+    d.comp[0] = pa; d.comp[1] = qa;
+    if (d.on && d.du * d.dv > maxpts) maxpts = d.du * d.dv;
+  }
+  const dim3 grid((unsigned)((maxpts + FDTD_BLOCK - 1) / FDTD_BLOCK), 12), block(FDTD_BLOCK);
+  hipLaunchKernelGGL(k_mur, grid, block, 0, s, c->p, m, mode);
+}
+
+void launch_post(fdtd_ctx* c, int kind, hipStream_t s) {
+  if (c->nfreq && c->nbox && (c->step % c->every) == 0 && c->box_maxpts[kind] > 0) {
+    long pts = c->box_maxpts[kind];
+    unsigned gx = (unsigned)((pts + FDTD_BLOCK - 1) / FDTD_BLOCK);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_dft, dim3(gx, (unsigned)c->nbox), dim3(FDTD_BLOCK), 0, s, c->p, kind, c->d_box, c->nfreq,
+                       c->every, c->nsamples, kind == FDTD_KIND_V ? c->tw_v : c->tw_i, c->d_step);
+  }
+  hipLaunchKernelGGL(k_post, dim3(1), dim3(FDTD_BLOCK), 0, s, c->p, kind, c->nsrc, c->src_off, c->src_comp, c->src_amp,
+                     c->src_delay, c->sig, c->nsig, c->nprobe, c->d_probe, c->d_step, c->d.max_steps);
+}
+
+void launch_energy(fdtd_ctx* c, hipStream_t s) {
+  hipMemsetAsync(c->d_energy, 0, 2 * sizeof(double), s);
+  hipLaunchKernelGGL(k_energy, dim3(1024), dim3(FDTD_BLOCK), 0, s, c->p, c->d_energy);
+}

@@ -1,0 +1,209 @@
+"""Assembly of one FDTD run: operator + boundaries + ports + recording surfaces -> engine(s).
+
+This is the host-side counterpart of what happens between the reference's ``prepare_*`` and the
+end of ``FDTD.Run(...)`` (antenna_sim/solver_fdtd_openems_fixed.py:171-220,280): everything the
+external engine derives from the scene before and while stepping.  The compute itself is
+libfdtd_hip.so (``lib`` argument = a library exporting include/fdtd_hip.h).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+import numpy as np
+
+from .constants import C0, EPS0, MU0
+from .grid import RectGrid
+from .scene import VoxelScene
+from .ecoperator import build_operator, ECOperator
+from .cpml import CPMLSpec, build_cpml
+from .excitation import gauss_pulse, dft_twiddles
+from .nf2ff import NF2FFBox
+from . import _capi
+from ._capi import Engine, KIND_V, KIND_I
+
+
+def slab_range(nz: int, world: int, rank: int):
+    """Contiguous z-planes [k0, k0+nk) of `rank`; the remainder goes to the first ranks."""
+    base, rem = divmod(nz, world)
+    k0 = rank * base + min(rank, rem)
+    return k0, base + (1 if rank < rem else 0)
+
+
+@dataclass
+class BoundarySpec:
+    """Per face (x-,x+,y-,y+,z-,z+): 'PEC', 'MUR' or 'CPML' (reference strings 'MUR' / 'PML_8',
+    solver_fdtd_openems_microstrip_3d.py:84)."""
+    kinds: Sequence[str] = ("CPML",) * 6
+    cpml_cells: int = 10
+    cpml: CPMLSpec = field(default_factory=CPMLSpec)
+
+    @classmethod
+    def parse(cls, boundary, cpml_cells: Optional[int] = None) -> "BoundarySpec":
+        if isinstance(boundary, BoundarySpec):
+            return boundary
+        names = [boundary] * 6 if isinstance(boundary, (str, int)) else list(boundary)
+        kinds, cells = [], cpml_cells
+        for b in names:
+            s = str(b).upper()
+            if s.startswith("MUR") or s == "2":
+                kinds.append("MUR")
+            elif s.startswith("PML") or s.startswith("CPML") or s == "3":
+                kinds.append("CPML")
+                if cells is None and "_" in s and s.split("_")[1].isdigit():
+                    cells = int(s.split("_")[1])
+            elif s in ("PEC", "0"):
+                kinds.append("PEC")
+            else:
+                raise ValueError(f"unsupported boundary '{b}'")
+        return cls(tuple(kinds), 8 if cells is None else cells)
+
+    def face_cells(self):
+        return tuple(self.cpml_cells if k == "CPML" else 0 for k in self.kinds)
+
+
+@dataclass
+class RunStats:
+    steps: int = 0
+    seconds: float = 0.0
+    mcells_per_s: float = 0.0
+    energy_db: float = 0.0
+    stopped_by_energy: bool = False
+
+
+class Simulation:
+    def __init__(self, grid: RectGrid, vox: VoxelScene, *, f0: float, fc: float, boundary="CPML",
+                 cpml_cells: Optional[int] = None, nr_ts: int = 30000, end_criteria: float = 1e-4,
+                 dt: Optional[float] = None, nf2ff_freqs: Optional[Sequence[float]] = None,
+                 nf2ff_inset: Optional[int] = None, dft_oversample: float = 4.0, use_classes: bool = True):
+        self.grid, self.vox = grid, vox
+        self.f0, self.fc = float(f0), float(fc)
+        self.bc = BoundarySpec.parse(boundary, cpml_cells)
+        self.nr_ts, self.end_criteria = int(nr_ts), float(end_criteria)
+        self.dt = grid.courant_dt() if dt is None else float(dt)
+        self.use_classes = use_classes
+        self.op: ECOperator = build_operator(grid, vox.eps_r, vox.kappa, vox.pec, self.dt, vox.lumped)
+        cells = self.bc.face_cells()
+        self.cpml = None
+        if any(cells):
+            spec = CPMLSpec(**{**self.bc.cpml.__dict__, "cells": cells})
+            self.cpml = build_cpml(grid, self.dt, spec)
+        self.mur_enable = np.array([1 if k == "MUR" else 0 for k in self.bc.kinds], np.int32)
+        self.mur_coeff = np.zeros(6, np.float32)
+        for f in range(6):
+            l = grid.lines[f // 2]
+            delta = (l[-1] - l[-2]) if f % 2 else (l[1] - l[0])
+            self.mur_coeff[f] = (C0 * self.dt - delta) / (C0 * self.dt + delta)
+        self.signal = gauss_pulse(self.f0, self.fc, self.dt)
+        # NF2FF recording
+        self.nf2ff_box: Optional[NF2FFBox] = None
+        self.nf2ff_freqs = None
+        if nf2ff_freqs is not None:
+            self.nf2ff_freqs = np.atleast_1d(np.asarray(nf2ff_freqs, float))
+            n = grid.shape
+            lo, hi = [], []
+            for a in range(3):
+                il = (cells[2 * a] + 2) if nf2ff_inset is None else nf2ff_inset
+                ih = (cells[2 * a + 1] + 2) if nf2ff_inset is None else nf2ff_inset
+                il = max(il, 3); ih = max(ih, 3)
+                lo.append(il); hi.append(n[a] - 1 - ih)
+            self.nf2ff_box = NF2FFBox(grid, lo, hi)
+            fmax = max(self.f0 + self.fc, float(np.max(self.nf2ff_freqs)))
+            self.dft_every = max(1, int(np.floor(1.0 / (2.0 * fmax * dft_oversample * self.dt))))
+            self.dft_nsamples = self.nr_ts // self.dft_every + 1
+        self.engine: Optional[Engine] = None
+        self.lib = None
+        self._port_probe_ids = []
+        self._nf_ids = []
+
+    # ---------------------------------------------------------------------------------------------
+    def build(self, lib, *, rank: int = 0, world: int = 1, device: int = 0, flags: int = 0) -> Engine:
+        g = self.grid
+        nx, ny, nz = g.shape
+        k0, nk = slab_range(nz, world, rank)
+        if nk < 2:
+            raise ValueError(f"slab of rank {rank} has {nk} planes; need >= 2")
+        e = Engine(lib, nx, ny, nz, self.dt, k0=k0, nk=nk, rank=rank, world=world, device=device,
+                   max_steps=self.nr_ts, flags=flags)
+        cls = self.op.classes(k0, nk) if self.use_classes else None
+        if cls is not None:
+            emet, hmet = self.op.metric_tables(k0, nk)
+            e.set_operator_classes(cls[0], cls[1], cls[2], emet, hmet)
+            self.operator_form = "classes"
+        else:
+            e.set_operator_raw(*self.op.raw(k0, nk))
+            self.operator_form = "raw"
+        if self.cpml is not None:
+            e.set_cpml(*self.cpml.for_slab(k0, nk))
+        if self.mur_enable.any():
+            e.set_mur(self.mur_enable, self.mur_coeff)
+        e.set_signal(self.signal)
+        self._port_probe_ids = []
+        for p in self.vox.ports:
+            if p.port.excite != 0:
+                e.add_source(p.src_idx, p.src_comp, p.src_amp,
+                             np.full(p.src_idx.size, p.port.delay_steps, np.int32))
+            uid = e.add_probe(KIND_V, p.v_idx, p.v_comp, p.v_w)
+            iid = e.add_probe(KIND_I, p.i_idx, p.i_comp, p.i_w)
+            self._port_probe_ids.append((uid, iid))
+        if self.nf2ff_box is not None:
+            tw_v = dft_twiddles(self.nf2ff_freqs, self.dt, self.dft_every, self.dft_nsamples, 0.0)
+            tw_i = dft_twiddles(self.nf2ff_freqs, self.dt, self.dft_every, self.dft_nsamples, 0.5)
+            e.set_dft(self.dft_every, tw_v, tw_i)
+            self._nf_ids = self.nf2ff_box.register(e)
+        self.engine, self.lib = e, lib
+        self.rank, self.world, self.device = rank, world, device
+        return e
+
+    # ---------------------------------------------------------------------------------------------
+    def run(self, *, max_steps: Optional[int] = None, check_every: int = 200, verbose: int = 0,
+            allreduce=None, log=print) -> RunStats:
+        """Step until nr_ts or until the field energy drops below end_criteria x its maximum
+        ([EXT] openEMS end criterion, EndCriteria=1e-4 at solver_fdtd_openems_fixed.py:171).
+        `allreduce(np.ndarray) -> np.ndarray` sums the two energy terms over ranks when world > 1."""
+        import time
+        e = self.engine
+        total = self.nr_ts if max_steps is None else min(max_steps, self.nr_ts)
+        emax, stats = 0.0, RunStats()
+        t0 = time.perf_counter()
+        done = e.step
+        while done < total:
+            n = min(check_every, total - done)
+            e.run(n)
+            done += n
+            sv, si = e.energy()
+            s = np.array([sv, si])
+            if allreduce is not None:
+                s = allreduce(s)
+            en = EPS0 * s[0] + MU0 * s[1]
+            emax = max(emax, en)
+            ratio = en / emax if emax > 0 else 1.0
+            stats.energy_db = 10.0 * np.log10(max(ratio, 1e-300))
+            if verbose:
+                el = time.perf_counter() - t0
+                log(f"[fdtd-hip] step {done:6d}/{total}  energy {stats.energy_db:7.2f} dB  "
+                    f"{self.grid.ncells * done / max(el, 1e-9) / 1e6:9.1f} MC/s")
+            if self.end_criteria > 0 and done >= len(self.signal) and ratio < self.end_criteria:
+                stats.stopped_by_energy = True
+                break
+        stats.steps = done
+        stats.seconds = time.perf_counter() - t0
+        stats.mcells_per_s = self.grid.ncells * done / max(stats.seconds, 1e-9) / 1e6
+        return stats
+
+    # ---------------------------------------------------------------------------------------------
+    def port_series(self, allreduce=None):
+        """[(u(t), i(t))] per port; i is sampled half a step after u."""
+        out = []
+        for uid, iid in self._port_probe_ids:
+            u, i = self.engine.get_probe(uid), self.engine.get_probe(iid)
+            if allreduce is not None:
+                u, i = allreduce(u), allreduce(i)
+            out.append((u, i))
+        return out
+
+    def nf2ff_boxes(self, allreduce=None):
+        boxes = self.nf2ff_box.collect(self.engine, self._nf_ids)
+        if allreduce is not None:
+            boxes = [allreduce(b) for b in boxes]
+        scale = self.dt * self.dft_every
+        return [b * scale for b in boxes]

@@ -1,0 +1,193 @@
+/*
+ * fdtd_hip.h — C ABI of libfdtd_hip.so, the MI355X (gfx950) EC-FDTD engine.
+ *
+ * This is the drop-in boundary for the one hot path of Veeryan/FDTD-solver-antennas:
+ * everything the reference delegates to the external openEMS engine behind
+ *
+ *     FDTD.Run(sim_path, verbose, cleanup)            antenna_sim/solver_fdtd_openems_fixed.py:280
+ *                                                     antenna_sim/solver_fdtd_openems_microstrip.py:401
+ *                                                     antenna_sim/solver_fdtd_openems_microstrip_3d.py:214
+ *                                                     antenna_sim/solver_fdtd_openems_microstrip_multi_3d.py:610
+ *                                                     antenna_sim/solver_fdtd_openems.py:289
+ *     nf2ff.CalcNF2FF(sim_path, f, theta, phi, center) antenna_sim/solver_fdtd_openems_fixed.py:296 (and :433/:225/:621/:301)
+ *     port.CalcPort(sim_path, f)                      antenna_sim/solver_fdtd_openems_microstrip.py:409 (dead upstream)
+ *
+ * The reference has no FFI of its own (it imports the openEMS Python module); the entry
+ * points below are what a ctypes binding for this path binds instead.
+ * Plain pointers and sizes only; no C++/torch types.  All functions return 0 on success
+ * and a negative FDTD_E_* code on failure (never throw, never abort); the message is
+ * available from fdtd_last_error().  A context is used by one host thread at a time.
+ *
+ * The same ABI is exported by oracle/libfdtd_oracle.so (plain-C CPU restatement, test
+ * infrastructure only) so every parity test drives both libraries through one wrapper.
+ *
+ * Conventions
+ * -----------
+ *  - Grid: nx*ny*nz mesh NODES (openEMS "numLines"); node (i,j,k) owns the three edges
+ *    leaving it in +x,+y,+z (voltages V = E*len) and the three dual faces (currents I = H*len~).
+ *    "cells" in the Mcells/s metric = nx*ny*nz, like openEMS's "MC/s".
+ *  - Host arrays are dense, x fastest: a[c][k][j][i] -> ((c*nk + k)*ny + j)*nx + i, c in {x,y,z}.
+ *  - z-slab decomposition: a context owns planes [k0, k0+nk) of the global grid; `nk`-sized
+ *    array arguments are LOCAL to the slab, index arguments (sources, probes, boxes) are GLOBAL
+ *    and are clipped to the slab by the library.
+ *  - Leapfrog step n (n = 0,1,...), identical operation order in the HIP and oracle builds:
+ *       1. Mur pre-pass            (boundary faces with Mur enabled)
+ *       2. V <- vv*V + vi*(curl I [CPML-stretched] )                       "E half-step"
+ *       3. Mur post+apply; V[e] += amp[e]*signal[n-delay[e]]; V-probes sample; V-DFT boxes accumulate
+ *       4. I <- ii*I + iv*(curl V [CPML-stretched] )                       "H half-step"
+ *       5. I-probes sample; I-DFT boxes accumulate; n <- n+1
+ *    with (x: cyclic y,z)
+ *       curlI_x = Iz(i,j,k) - Iz(i,j-1,k) - Iy(i,j,k) + Iy(i,j,k-1)
+ *       curlV_x = Vz(i,j,k) - Vz(i,j+1,k) - Vy(i,j,k) + Vy(i,j,k+1)
+ *    Out-of-range neighbours are only ever multiplied by zero coefficients.
+ */
+#ifndef FDTD_HIP_H
+#define FDTD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDTD_ABI_VERSION 1
+
+enum {
+  FDTD_OK = 0,
+  FDTD_E_ARG = -1,      /* bad argument / shape mismatch */
+  FDTD_E_STATE = -2,    /* call order (e.g. run before operator set) */
+  FDTD_E_DEVICE = -3,   /* HIP / RCCL runtime error */
+  FDTD_E_NOMEM = -4,
+  FDTD_E_UNSUPPORTED = -5
+};
+
+enum { FDTD_KIND_V = 0, FDTD_KIND_I = 1 };           /* edge voltages (E) / face currents (H) */
+enum { FDTD_PHASE_E = 0, FDTD_PHASE_H = 1 };
+enum { FDTD_HALO_H_UP = 0, FDTD_HALO_E_DOWN = 1 };   /* Ix,Iy top plane -> rank+1 ; Vx,Vy bottom plane -> rank-1 */
+
+/* Kernel selection (fdtd_desc.flags) — all variants compute bit-identical results. */
+enum {
+  FDTD_FLAG_KERNEL_AUTO   = 0,
+  FDTD_FLAG_KERNEL_DIRECT = 1,   /* one thread = 4 x-cells, neighbours through L1/L2 */
+  FDTD_FLAG_KERNEL_LDS    = 2,   /* LDS-tiled, z-marching */
+  FDTD_FLAG_KERNEL_MASK   = 0xF,
+  FDTD_FLAG_NO_GRAPH      = 0x10 /* do not capture the step loop into a hipGraph */
+};
+
+typedef struct fdtd_ctx fdtd_ctx;
+
+typedef struct fdtd_desc {
+  int32_t nx, ny, nz;     /* global node counts */
+  int32_t k0, nk;         /* owned z-planes [k0, k0+nk) */
+  int32_t rank, world;    /* position in the z-slab chain (rank r neighbours r-1 below, r+1 above) */
+  int32_t device;         /* HIP device ordinal */
+  int32_t max_steps;      /* capacity of the probe time series */
+  uint32_t flags;
+  double dt;              /* time step [s] (informational; all coefficients arrive pre-multiplied) */
+} fdtd_desc;
+
+typedef struct fdtd_profile {
+  double ms_total;        /* stream time for the profiled steps, HIP events */
+  double ms_update_e;     /* average duration of one E half-step main kernel launch */
+  double ms_update_h;     /* average duration of one H half-step main kernel launch */
+  int32_t launches_e;     /* launches averaged */
+  int32_t launches_h;
+  int32_t steps;
+  int32_t reserved;
+} fdtd_profile;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int  fdtd_version(void);
+int  fdtd_device_count(void);
+const char* fdtd_backend(void);                       /* "hip:gfx950" or "oracle:cpu" */
+int  fdtd_create(const fdtd_desc* desc, fdtd_ctx** out);
+void fdtd_destroy(fdtd_ctx* ctx);
+const char* fdtd_last_error(const fdtd_ctx* ctx);     /* ctx may be NULL: last error of a failed create */
+
+/* ---- operator (replaces openEMS's operator set-up inside FDTD.Run) ---------------------- */
+/* Raw EC coefficients, each [3][nk][ny][nx]. */
+int fdtd_set_operator_raw(fdtd_ctx* ctx, const float* vv, const float* vi,
+                          const float* ii, const float* iv);
+/* Compressed form: one class byte per edge + separable 1-D metric tables.
+ *   vv   = cls_vv[c]
+ *   vi_x = cls_m[c] * (ex[i] * (ey[j] * ez[k]))      with (ex,ey,ez) = emet rows of component x
+ *   ii   = 1
+ *   iv_x = hx[i] * (hy[j] * hz[k])                   (float32, exactly this association)
+ * ecls: [3][nk][ny][nx];  emet/hmet: [3 comps][nx + ny + nk] (x table, then y, then LOCAL z). */
+int fdtd_set_operator_classes(fdtd_ctx* ctx, const uint8_t* ecls, int ncls,
+                              const float* cls_vv, const float* cls_m,
+                              const float* emet, const float* hmet);
+
+/* ---- absorbing boundaries --------------------------------------------------------------- */
+/* CPML.  slot_a[idx] >= 0 gives the psi storage slot of index idx along axis a (-1: no psi).
+ * coef: [3 axes][2 (0: E-located = node, 1: H-located = half node)][3 (b, c, 1/kappa)][n_a]
+ * stored axis after axis with n_x = nx, n_y = ny, n_z = nk (LOCAL).  Outside the layers b=c=0, 1/kappa=1.
+ *   psi = b*psi + c*d ;  term = (1/kappa)*d + psi     for every difference d along that axis. */
+int fdtd_set_cpml(fdtd_ctx* ctx, const int32_t* slot_x, const int32_t* slot_y, const int32_t* slot_z,
+                  int nslot_x, int nslot_y, int nslot_z, const float* coef);
+/* First-order Mur on faces {x-,x+,y-,y+,z-,z+}; coeff = (c*dt - d)/(c*dt + d). z faces apply on the
+ * ranks that own plane 0 / nz-1. */
+int fdtd_set_mur(fdtd_ctx* ctx, const int32_t enable[6], const float coeff[6]);
+
+/* ---- excitation, probes, frequency-domain recording ------------------------------------- */
+int fdtd_set_signal(fdtd_ctx* ctx, const float* sig, int n);
+/* V[comp[e]][idx[e]] += amp[e] * sig[step - delay[e]];  idx = (k*ny + j)*nx + i, GLOBAL k. */
+int fdtd_add_source(fdtd_ctx* ctx, int n, const int64_t* idx, const int8_t* comp,
+                    const float* amp, const int32_t* delay);
+/* value[step] = sum_e w[e] * field[comp[e]][idx[e]] over the edges this slab owns. */
+int fdtd_add_probe(fdtd_ctx* ctx, int kind, int n, const int64_t* idx, const int8_t* comp,
+                   const float* w, int* id_out);
+int fdtd_get_probe(fdtd_ctx* ctx, int id, double* out, int cap, int* n_out);
+/* Running DFT: every `every` steps (steps every*s, s = 0..), for each registered box,
+ *   acc[f] += field * tw[s][f]   (complex double; tw_v for V samples, tw_i for I samples).
+ * tw_*: [nsamples][nfreq][2]. */
+int fdtd_set_dft(fdtd_ctx* ctx, int nfreq, int every, int nsamples,
+                 const double* tw_v, const double* tw_i);
+/* lo/hi: inclusive GLOBAL node index box. */
+int fdtd_add_dft_box(fdtd_ctx* ctx, int kind, int comp, const int32_t lo[3], const int32_t hi[3],
+                     int* id_out);
+/* Returns the part of the box inside this slab: lo_own/hi_own (GLOBAL indices; hi<lo if empty) and
+ * out[nfreq][kk][jj][ii][2].  out may be NULL to query the extent only. */
+int fdtd_get_dft_box(fdtd_ctx* ctx, int id, double* out, int32_t lo_own[3], int32_t hi_own[3]);
+
+/* ---- time stepping ------------------------------------------------------------------------ */
+/* Run nsteps full leapfrog steps (halo exchange inside when world > 1 and a communicator is set).
+ * Blocks until the device is idle. */
+int fdtd_run(fdtd_ctx* ctx, int nsteps);
+/* Same, but brackets the loop and every main-kernel launch with HIP events on the engine's stream. */
+int fdtd_run_profiled(fdtd_ctx* ctx, int nsteps, fdtd_profile* out);
+int fdtd_get_step(fdtd_ctx* ctx, int64_t* step);
+/* sums[0] = sum V^2, sums[1] = sum I^2 over the owned planes. */
+int fdtd_energy(fdtd_ctx* ctx, double sums[2]);
+
+/* ---- halo transport ----------------------------------------------------------------------- */
+/* (a) RCCL over xGMI, owned by the library.  Rank 0 creates the id, the host program ships the
+ *     128 bytes to every rank (e.g. torch.distributed broadcast), every rank calls comm_init. */
+int fdtd_comm_unique_id(void* out128);
+int fdtd_comm_init(fdtd_ctx* ctx, const void* uid128);
+/* (b) External transport (MPI, gloo, ...): one half-step at a time, halos through host buffers.
+ *     buf: [2][ny][nx] floats = the two tangential components (x then y) of one plane. */
+int fdtd_half_step(fdtd_ctx* ctx, int phase);
+int fdtd_halo_get(fdtd_ctx* ctx, int which, float* buf);
+int fdtd_halo_put(fdtd_ctx* ctx, int which, const float* buf);
+
+/* ---- field access (parity / debugging) ---------------------------------------------------- */
+int fdtd_get_field(fdtd_ctx* ctx, int kind, int comp, float* out);      /* [nk][ny][nx] */
+int fdtd_set_field(fdtd_ctx* ctx, int kind, int comp, const float* in);
+
+/* ---- near-to-far-field transform (replaces nf2ff.CalcNF2FF's radiation integral) ---------- */
+/* Surface equivalence: npts quadrature points with position pos[p][3] (relative to the phase
+ * centre, metres) and area-weighted complex equivalent currents Js = n x H * dA, Ms = -n x E * dA,
+ * [p][3][2].  For every direction a: r^ = (sin th cos ph, sin th sin ph, cos th)
+ *   N = sum_p Js_p exp(+j k r^.pos_p),  L = sum_p Ms_p exp(+j k r^.pos_p)
+ *   Eth[a] = -j k/(4 pi) (L_ph + eta0 N_th),  Eph[a] = +j k/(4 pi) (L_th - eta0 N_ph)   (r*E, far zone)
+ * Eth/Eph: [nang][2]. */
+int fdtd_farfield(int device, int npts, const double* pos, const double* Js, const double* Ms,
+                  double k_wave, int nang, const double* theta, const double* phi,
+                  double* Eth, double* Eph);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDTD_HIP_H */

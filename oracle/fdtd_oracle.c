@@ -1,0 +1,659 @@
+/*
+ * fdtd_oracle.c — CPU restatement of the EC-FDTD time-stepping path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (fdtd-solver-antennas_amd/) never does and fails loudly without libfdtd_hip.so.
+ *
+ * PARITY UNPINNED against openEMS: the arithmetic of this path is not in /root/reference — it
+ * lives in the third-party, un-vendored, un-pinned openEMS/CSXCAD install that the reference
+ * imports at run time (antenna_sim/solver_fdtd_openems_fixed.py:131-133) and calls at
+ *   FDTD.Run(...)        solver_fdtd_openems_fixed.py:280, _microstrip.py:401, _microstrip_3d.py:214,
+ *                        _microstrip_multi_3d.py:610, solver_fdtd_openems.py:289
+ *   nf2ff.CalcNF2FF(...) solver_fdtd_openems_fixed.py:296 (+ :433, :225, :621, :301)
+ * The reference ships no golden vectors for it (test_openems.py:101-108 only prints SUCCESS).
+ * This file therefore restates the PUBLISHED equivalent-circuit FDTD algorithm that engine
+ * implements (Rennings et al., EC-FDTD; Liebig et al., "openEMS – a free and open source
+ * equivalent-circuit (EC) FDTD simulation platform", IJNM 2013), CPML after Roden & Gedney 2000,
+ * first-order Mur, and the surface-equivalence NF2FF integral (Balanis, Antenna Theory §12),
+ * and is pinned by physics known-answer tests in tests/ (cavity eigenfrequency, CPML
+ * reflection, matched port, energy decay), not by openEMS outputs.
+ *
+ * It exports the ABI of include/fdtd_hip.h with the float32 operation order spelled out with
+ * explicit fmaf() so that the HIP kernels can be compared BIT FOR BIT:
+ *     psi  = fmaf(b, psi, c*d)            t = fmaf(ik, d, psi)
+ *     curl = t1 - t2                      F = fmaf(cA, F, cB*curl)
+ * Build with -ffp-contract=off -mfma (oracle/Makefile).
+ */
+#include "../include/fdtd_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+
+#define MAX_PROBES 64
+#define MAX_BOXES 64
+
+typedef struct {
+  int kind, n;
+  int64_t* off; /* local flat offset into the padded field array */
+  int8_t* comp;
+  float* w;
+  double* series;
+} probe_t;
+
+typedef struct {
+  int kind, comp;
+  int32_t lo[3], hi[3];     /* global box */
+  int32_t olo[3], ohi[3];   /* owned part (global indices), empty if ohi<olo */
+  size_t npts;
+  double* acc;              /* [nfreq][npts][2] */
+} dftbox_t;
+
+struct fdtd_ctx {
+  fdtd_desc d;
+  size_t plane, nloc;       /* ny*nx, nk*plane */
+  float* Vb[3]; float* Ib[3]; /* base allocations, (nk+2) planes */
+  float* V[3];  float* I[3];  /* pointers to local plane 0 */
+  float *vv, *vi, *ii, *iv;   /* [3][nloc] */
+  int have_op;
+  /* CPML */
+  int have_cpml;
+  int32_t *slot[3]; int nslot[3];
+  float* coef;               /* [3][2][3][n_a] */
+  size_t coef_off[3];        /* start of each axis block */
+  float* psiE[3][2];         /* comp c, which (0: axis a1=(c+1)%3, 1: axis a2=(c+2)%3) */
+  float* psiH[3][2];
+  /* Mur */
+  int mur_on[6]; float mur_c[6];
+  float* mur_st[6][2];
+  /* excitation */
+  float* sig; int nsig;
+  int nsrc; int64_t* src_off; int8_t* src_comp; float* src_amp; int32_t* src_delay;
+  /* probes, dft */
+  int nprobe; probe_t probe[MAX_PROBES];
+  int nbox; dftbox_t box[MAX_BOXES];
+  int nfreq, every, nsamples; double *tw_v, *tw_i;
+  int64_t step;
+  char err[512];
+};
+
+static __thread char g_err[512];
+
+static int fail(fdtd_ctx* c, int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt);
+  vsnprintf(c ? c->err : g_err, 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int fdtd_version(void) { return FDTD_ABI_VERSION; }
+int fdtd_device_count(void) { return 0; }
+const char* fdtd_backend(void) { return "oracle:cpu"; }
+const char* fdtd_last_error(const fdtd_ctx* c) { return c ? c->err : g_err; }
+
+static int n_axis(const fdtd_ctx* c, int a) { return a == 0 ? c->d.nx : a == 1 ? c->d.ny : c->d.nk; }
+
+int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
+  if (!d || !out) return fail(NULL, FDTD_E_ARG, "null argument");
+  if (d->nx < 2 || d->ny < 2 || d->nz < 2 || d->nk < 1 || d->k0 < 0 || d->k0 + d->nk > d->nz)
+    return fail(NULL, FDTD_E_ARG, "bad grid/slab %dx%dx%d k0=%d nk=%d", d->nx, d->ny, d->nz, d->k0, d->nk);
+  fdtd_ctx* c = (fdtd_ctx*)calloc(1, sizeof(*c));
+  if (!c) return fail(NULL, FDTD_E_NOMEM, "calloc");
+  c->d = *d;
+  c->plane = (size_t)d->nx * d->ny;
+  c->nloc = c->plane * d->nk;
+  for (int n = 0; n < 3; ++n) {
+    c->Vb[n] = (float*)calloc(c->plane * (d->nk + 2), sizeof(float));
+    c->Ib[n] = (float*)calloc(c->plane * (d->nk + 2), sizeof(float));
+    if (!c->Vb[n] || !c->Ib[n]) { fdtd_destroy(c); return fail(NULL, FDTD_E_NOMEM, "fields"); }
+    c->V[n] = c->Vb[n] + c->plane;
+    c->I[n] = c->Ib[n] + c->plane;
+  }
+  *out = c;
+  return FDTD_OK;
+}
+
+void fdtd_destroy(fdtd_ctx* c) {
+  if (!c) return;
+  for (int n = 0; n < 3; ++n) {
+    free(c->Vb[n]); free(c->Ib[n]); free(c->slot[n]);
+    for (int w = 0; w < 2; ++w) { free(c->psiE[n][w]); free(c->psiH[n][w]); }
+  }
+  free(c->vv); free(c->vi); free(c->ii); free(c->iv); free(c->coef);
+  for (int f = 0; f < 6; ++f) { free(c->mur_st[f][0]); free(c->mur_st[f][1]); }
+  free(c->sig); free(c->src_off); free(c->src_comp); free(c->src_amp); free(c->src_delay);
+  for (int p = 0; p < c->nprobe; ++p) { free(c->probe[p].off); free(c->probe[p].comp); free(c->probe[p].w); free(c->probe[p].series); }
+  for (int b = 0; b < c->nbox; ++b) free(c->box[b].acc);
+  free(c->tw_v); free(c->tw_i);
+  free(c);
+}
+
+static int alloc_op(fdtd_ctx* c) {
+  size_t n = 3 * c->nloc * sizeof(float);
+  if (!c->vv) { c->vv = malloc(n); c->vi = malloc(n); c->ii = malloc(n); c->iv = malloc(n); }
+  return (c->vv && c->vi && c->ii && c->iv) ? 0 : -1;
+}
+
+int fdtd_set_operator_raw(fdtd_ctx* c, const float* vv, const float* vi, const float* ii, const float* iv) {
+  if (!c || !vv || !vi || !ii || !iv) return fail(c, FDTD_E_ARG, "null operator array");
+  if (alloc_op(c)) return fail(c, FDTD_E_NOMEM, "operator");
+  size_t n = 3 * c->nloc * sizeof(float);
+  memcpy(c->vv, vv, n); memcpy(c->vi, vi, n); memcpy(c->ii, ii, n); memcpy(c->iv, iv, n);
+  c->have_op = 1;
+  return FDTD_OK;
+}
+
+/* Expansion of the compressed operator with the float32 association fixed by fdtd_hip.h. */
+int fdtd_set_operator_classes(fdtd_ctx* c, const uint8_t* ecls, int ncls, const float* cls_vv,
+                              const float* cls_m, const float* emet, const float* hmet) {
+  if (!c || !ecls || !cls_vv || !cls_m || !emet || !hmet || ncls < 1 || ncls > 256)
+    return fail(c, FDTD_E_ARG, "bad class operator");
+  if (alloc_op(c)) return fail(c, FDTD_E_NOMEM, "operator");
+  const int nx = c->d.nx, ny = c->d.ny, nk = c->d.nk;
+  const int tl = nx + ny + nk;
+  for (int n = 0; n < 3; ++n) {
+    const float *ex = emet + n * tl, *ey = ex + nx, *ez = ey + ny;
+    const float *hx = hmet + n * tl, *hy = hx + nx, *hz = hy + ny;
+    for (int k = 0; k < nk; ++k)
+      for (int j = 0; j < ny; ++j) {
+        const float eyz = ey[j] * ez[k];
+        const float hyz = hy[j] * hz[k];
+        size_t row = n * c->nloc + ((size_t)k * ny + j) * nx;
+        for (int i = 0; i < nx; ++i) {
+          int cl = ecls[row + i];
+          if (cl >= ncls) return fail(c, FDTD_E_ARG, "class %d >= ncls %d", cl, ncls);
+          c->vv[row + i] = cls_vv[cl];
+          c->vi[row + i] = cls_m[cl] * (ex[i] * eyz);
+          c->ii[row + i] = 1.0f;
+          c->iv[row + i] = hx[i] * hyz;
+        }
+      }
+  }
+  c->have_op = 1;
+  return FDTD_OK;
+}
+
+/* psi extents: axis x -> [nk][ny][nslot_x]; y -> [nk][nslot_y][nx]; z -> [nslot_z][ny][nx] */
+static size_t psi_size(const fdtd_ctx* c, int a) {
+  if (c->nslot[a] <= 0) return 0;
+  if (a == 0) return (size_t)c->d.nk * c->d.ny * c->nslot[0];
+  if (a == 1) return (size_t)c->d.nk * c->nslot[1] * c->d.nx;
+  return (size_t)c->nslot[2] * c->d.ny * c->d.nx;
+}
+
+int fdtd_set_cpml(fdtd_ctx* c, const int32_t* sx, const int32_t* sy, const int32_t* sz,
+                  int nsx, int nsy, int nsz, const float* coef) {
+  if (!c || !sx || !sy || !sz || !coef) return fail(c, FDTD_E_ARG, "null cpml argument");
+  const int32_t* s[3] = {sx, sy, sz};
+  int ns[3] = {nsx, nsy, nsz};
+  size_t off = 0;
+  for (int a = 0; a < 3; ++a) {
+    int n = n_axis(c, a);
+    free(c->slot[a]);
+    c->slot[a] = (int32_t*)malloc(n * sizeof(int32_t));
+    memcpy(c->slot[a], s[a], n * sizeof(int32_t));
+    for (int q = 0; q < n; ++q)
+      if (s[a][q] >= ns[a]) return fail(c, FDTD_E_ARG, "cpml slot out of range on axis %d", a);
+    c->nslot[a] = ns[a];
+    c->coef_off[a] = off;
+    off += (size_t)6 * n;
+  }
+  free(c->coef);
+  c->coef = (float*)malloc(off * sizeof(float));
+  memcpy(c->coef, coef, off * sizeof(float));
+  for (int n = 0; n < 3; ++n)
+    for (int w = 0; w < 2; ++w) {
+      int a = (n + 1 + w) % 3;
+      free(c->psiE[n][w]); free(c->psiH[n][w]);
+      size_t sz_ = psi_size(c, a);
+      c->psiE[n][w] = sz_ ? (float*)calloc(sz_, sizeof(float)) : NULL;
+      c->psiH[n][w] = sz_ ? (float*)calloc(sz_, sizeof(float)) : NULL;
+    }
+  c->have_cpml = 1;
+  return FDTD_OK;
+}
+
+static const float* cpml_tab(const fdtd_ctx* c, int a, int eh, int which) {
+  return c->coef + c->coef_off[a] + (size_t)(eh * 3 + which) * n_axis(c, a);
+}
+
+int fdtd_set_mur(fdtd_ctx* c, const int32_t enable[6], const float coeff[6]) {
+  if (!c || !enable || !coeff) return fail(c, FDTD_E_ARG, "null mur argument");
+  for (int f = 0; f < 6; ++f) {
+    int a = f / 2;
+    int on = enable[f] != 0;
+    if (a == 2) { /* z faces live on the rank owning the boundary plane */
+      int b = (f & 1) ? c->d.nz - 1 : 0;
+      if (b < c->d.k0 || b >= c->d.k0 + c->d.nk) on = 0;
+      else if (on && c->d.nk < 2) return fail(c, FDTD_E_UNSUPPORTED, "Mur z face needs nk >= 2");
+    }
+    c->mur_on[f] = on; c->mur_c[f] = coeff[f];
+    size_t n = a == 0 ? (size_t)c->d.nk * c->d.ny : a == 1 ? (size_t)c->d.nk * c->d.nx : c->plane;
+    for (int t = 0; t < 2; ++t) {
+      free(c->mur_st[f][t]);
+      c->mur_st[f][t] = on ? (float*)calloc(n, sizeof(float)) : NULL;
+    }
+  }
+  return FDTD_OK;
+}
+
+int fdtd_set_signal(fdtd_ctx* c, const float* sig, int n) {
+  if (!c || !sig || n < 1) return fail(c, FDTD_E_ARG, "bad signal");
+  free(c->sig);
+  c->sig = (float*)malloc(n * sizeof(float));
+  memcpy(c->sig, sig, n * sizeof(float));
+  c->nsig = n;
+  return FDTD_OK;
+}
+
+/* global flat node index -> local offset; returns -1 if the node's plane is not owned */
+static int64_t to_local(const fdtd_ctx* c, int64_t g) {
+  int64_t k = g / (int64_t)c->plane;
+  if (g < 0 || k >= c->d.nz) return -2;
+  if (k < c->d.k0 || k >= c->d.k0 + c->d.nk) return -1;
+  return g - (int64_t)c->d.k0 * (int64_t)c->plane;
+}
+
+int fdtd_add_source(fdtd_ctx* c, int n, const int64_t* idx, const int8_t* comp, const float* amp, const int32_t* delay) {
+  if (!c || n < 0 || (n && (!idx || !comp || !amp || !delay))) return fail(c, FDTD_E_ARG, "bad source");
+  int tot = c->nsrc + n;
+  c->src_off = realloc(c->src_off, tot * sizeof(int64_t));
+  c->src_comp = realloc(c->src_comp, tot * sizeof(int8_t));
+  c->src_amp = realloc(c->src_amp, tot * sizeof(float));
+  c->src_delay = realloc(c->src_delay, tot * sizeof(int32_t));
+  for (int e = 0; e < n; ++e) {
+    int64_t l = to_local(c, idx[e]);
+    if (l == -2 || comp[e] < 0 || comp[e] > 2) return fail(c, FDTD_E_ARG, "source edge %d out of grid", e);
+    if (l < 0) continue;
+    c->src_off[c->nsrc] = l; c->src_comp[c->nsrc] = comp[e];
+    c->src_amp[c->nsrc] = amp[e]; c->src_delay[c->nsrc] = delay[e];
+    c->nsrc++;
+  }
+  return FDTD_OK;
+}
+
+int fdtd_add_probe(fdtd_ctx* c, int kind, int n, const int64_t* idx, const int8_t* comp, const float* w, int* id_out) {
+  if (!c || n < 0 || (n && (!idx || !comp || !w)) || (kind != 0 && kind != 1)) return fail(c, FDTD_E_ARG, "bad probe");
+  if (c->nprobe >= MAX_PROBES) return fail(c, FDTD_E_NOMEM, "too many probes");
+  probe_t* p = &c->probe[c->nprobe];
+  memset(p, 0, sizeof(*p));
+  p->kind = kind;
+  p->off = malloc((n + 1) * sizeof(int64_t)); p->comp = malloc(n + 1); p->w = malloc((n + 1) * sizeof(float));
+  p->series = calloc(c->d.max_steps > 0 ? c->d.max_steps : 1, sizeof(double));
+  for (int e = 0; e < n; ++e) {
+    int64_t l = to_local(c, idx[e]);
+    if (l == -2 || comp[e] < 0 || comp[e] > 2) return fail(c, FDTD_E_ARG, "probe edge %d out of grid", e);
+    if (l < 0) continue;
+    p->off[p->n] = l; p->comp[p->n] = comp[e]; p->w[p->n] = w[e]; p->n++;
+  }
+  if (id_out) *id_out = c->nprobe;
+  c->nprobe++;
+  return FDTD_OK;
+}
+
+int fdtd_get_probe(fdtd_ctx* c, int id, double* out, int cap, int* n_out) {
+  if (!c || id < 0 || id >= c->nprobe) return fail(c, FDTD_E_ARG, "bad probe id");
+  int n = (int)(c->step < c->d.max_steps ? c->step : c->d.max_steps);
+  if (n_out) *n_out = n;
+  if (out) memcpy(out, c->probe[id].series, (size_t)(n < cap ? n : cap) * sizeof(double));
+  return FDTD_OK;
+}
+
+int fdtd_set_dft(fdtd_ctx* c, int nfreq, int every, int nsamples, const double* tw_v, const double* tw_i) {
+  if (!c || nfreq < 1 || every < 1 || nsamples < 1 || !tw_v || !tw_i) return fail(c, FDTD_E_ARG, "bad dft setup");
+  if (c->nbox) return fail(c, FDTD_E_STATE, "set_dft must precede add_dft_box");
+  size_t n = (size_t)nsamples * nfreq * 2;
+  free(c->tw_v); free(c->tw_i);
+  c->tw_v = malloc(n * sizeof(double)); c->tw_i = malloc(n * sizeof(double));
+  memcpy(c->tw_v, tw_v, n * sizeof(double)); memcpy(c->tw_i, tw_i, n * sizeof(double));
+  c->nfreq = nfreq; c->every = every; c->nsamples = nsamples;
+  return FDTD_OK;
+}
+
+int fdtd_add_dft_box(fdtd_ctx* c, int kind, int comp, const int32_t lo[3], const int32_t hi[3], int* id_out) {
+  if (!c || !lo || !hi || comp < 0 || comp > 2 || (kind != 0 && kind != 1)) return fail(c, FDTD_E_ARG, "bad dft box");
+  if (!c->nfreq) return fail(c, FDTD_E_STATE, "set_dft first");
+  if (c->nbox >= MAX_BOXES) return fail(c, FDTD_E_NOMEM, "too many dft boxes");
+  const int dims[3] = {c->d.nx, c->d.ny, c->d.nz};
+  for (int a = 0; a < 3; ++a)
+    if (lo[a] < 0 || hi[a] >= dims[a] || hi[a] < lo[a]) return fail(c, FDTD_E_ARG, "dft box outside grid");
+  dftbox_t* b = &c->box[c->nbox];
+  memset(b, 0, sizeof(*b));
+  b->kind = kind; b->comp = comp;
+  for (int a = 0; a < 3; ++a) { b->lo[a] = lo[a]; b->hi[a] = hi[a]; b->olo[a] = lo[a]; b->ohi[a] = hi[a]; }
+  if (b->olo[2] < c->d.k0) b->olo[2] = c->d.k0;
+  if (b->ohi[2] > c->d.k0 + c->d.nk - 1) b->ohi[2] = c->d.k0 + c->d.nk - 1;
+  b->npts = b->ohi[2] < b->olo[2] ? 0 :
+      (size_t)(b->ohi[0] - b->olo[0] + 1) * (b->ohi[1] - b->olo[1] + 1) * (b->ohi[2] - b->olo[2] + 1);
+  b->acc = b->npts ? calloc(b->npts * c->nfreq * 2, sizeof(double)) : NULL;
+  if (id_out) *id_out = c->nbox;
+  c->nbox++;
+  return FDTD_OK;
+}
+
+int fdtd_get_dft_box(fdtd_ctx* c, int id, double* out, int32_t lo_own[3], int32_t hi_own[3]) {
+  if (!c || id < 0 || id >= c->nbox) return fail(c, FDTD_E_ARG, "bad dft box id");
+  dftbox_t* b = &c->box[id];
+  for (int a = 0; a < 3; ++a) { if (lo_own) lo_own[a] = b->olo[a]; if (hi_own) hi_own[a] = b->ohi[a]; }
+  if (out && b->npts) memcpy(out, b->acc, b->npts * c->nfreq * 2 * sizeof(double));
+  return FDTD_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Half-steps.  [EXT] openEMS engine UpdateVoltages/UpdateCurrents (SURVEY §2.2 N1,N2) with the
+ * CPML auxiliary fields fused in (N7: the north-star mandates CPML where openEMS has UPML).
+ * ---------------------------------------------------------------------------------------- */
+
+/* CPML transform of one row of differences d[] taken along axis a (in place -> stretched term). */
+static void cpml_row(const fdtd_ctx* c, int a, int eh, float* psi_arr, int j, int k, float* d) {
+  const int nx = c->d.nx, ny = c->d.ny;
+  const float *B = cpml_tab(c, a, eh, 0), *C = cpml_tab(c, a, eh, 1), *K = cpml_tab(c, a, eh, 2);
+  if (a == 0) {
+    const int ns = c->nslot[0];
+    float* psi = psi_arr + ((size_t)k * ny + j) * ns;
+    for (int i = 0; i < nx; ++i) {
+      int s = c->slot[0][i];
+      if (s < 0) continue;
+      float p = fmaf(B[i], psi[s], C[i] * d[i]);
+      psi[s] = p;
+      d[i] = fmaf(K[i], d[i], p);
+    }
+  } else {
+    int q = a == 1 ? j : k;
+    int s = c->slot[a][q];
+    if (s < 0) return;
+    float* psi = a == 1 ? psi_arr + ((size_t)k * c->nslot[1] + s) * nx
+                        : psi_arr + ((size_t)s * ny + j) * nx;
+    const float b = B[q], cc = C[q], kk = K[q];
+    for (int i = 0; i < nx; ++i) {
+      float p = fmaf(b, psi[i], cc * d[i]);
+      psi[i] = p;
+      d[i] = fmaf(kk, d[i], p);
+    }
+  }
+}
+
+static void update_E(fdtd_ctx* c) {
+  const int nx = c->d.nx, ny = c->d.ny, nk = c->d.nk;
+  const ptrdiff_t st[3] = {1, nx, (ptrdiff_t)c->plane};
+#pragma omp parallel
+  {
+    float* d1 = (float*)malloc(2 * nx * sizeof(float));
+    float* d2 = d1 + nx;
+#pragma omp for collapse(2) schedule(static)
+    for (int k = 0; k < nk; ++k)
+      for (int j = 0; j < ny; ++j) {
+        const size_t row = ((size_t)k * ny + j) * nx;
+        for (int n = 0; n < 3; ++n) {
+          const int a1 = (n + 1) % 3, a2 = (n + 2) % 3;
+          const float* F2 = c->I[a2] + row; /* differenced along a1 */
+          const float* F1 = c->I[a1] + row; /* differenced along a2 */
+          for (int i = 0; i < nx; ++i) {
+            d1[i] = F2[i] - F2[i - st[a1]];
+            d2[i] = F1[i] - F1[i - st[a2]];
+          }
+          if (c->have_cpml) {
+            cpml_row(c, a1, 0, c->psiE[n][0], j, k, d1);
+            cpml_row(c, a2, 0, c->psiE[n][1], j, k, d2);
+          }
+          float* V = c->V[n] + row;
+          const float* vv = c->vv + n * c->nloc + row;
+          const float* vi = c->vi + n * c->nloc + row;
+          for (int i = 0; i < nx; ++i) V[i] = fmaf(vv[i], V[i], vi[i] * (d1[i] - d2[i]));
+        }
+      }
+    free(d1);
+  }
+}
+
+static void update_H(fdtd_ctx* c) {
+  const int nx = c->d.nx, ny = c->d.ny, nk = c->d.nk;
+  const ptrdiff_t st[3] = {1, nx, (ptrdiff_t)c->plane};
+#pragma omp parallel
+  {
+    float* d1 = (float*)malloc(2 * nx * sizeof(float));
+    float* d2 = d1 + nx;
+#pragma omp for collapse(2) schedule(static)
+    for (int k = 0; k < nk; ++k)
+      for (int j = 0; j < ny; ++j) {
+        const size_t row = ((size_t)k * ny + j) * nx;
+        for (int n = 0; n < 3; ++n) {
+          const int a1 = (n + 1) % 3, a2 = (n + 2) % 3;
+          const float* F2 = c->V[a2] + row;
+          const float* F1 = c->V[a1] + row;
+          for (int i = 0; i < nx; ++i) {
+            d1[i] = F2[i] - F2[i + st[a1]];
+            d2[i] = F1[i] - F1[i + st[a2]];
+          }
+          if (c->have_cpml) {
+            cpml_row(c, a1, 1, c->psiH[n][0], j, k, d1);
+            cpml_row(c, a2, 1, c->psiH[n][1], j, k, d2);
+          }
+          float* I = c->I[n] + row;
+          const float* ii = c->ii + n * c->nloc + row;
+          const float* iv = c->iv + n * c->nloc + row;
+          for (int i = 0; i < nx; ++i) I[i] = fmaf(ii[i], I[i], iv[i] * (d1[i] - d2[i]));
+        }
+      }
+    free(d1);
+  }
+}
+
+/* First-order Mur ABC, [EXT] openEMS Engine_Ext_Mur_ABC pre/post/apply.
+ * mode 0: pre (before the E update), 1: post (after it), 2: apply. */
+static void mur_pass(fdtd_ctx* c, int mode) {
+  const int nx = c->d.nx, ny = c->d.ny, nk = c->d.nk;
+  const ptrdiff_t st[3] = {1, nx, (ptrdiff_t)c->plane};
+  const int dim[3] = {nx, ny, nk};
+  for (int f = 0; f < 6; ++f) {
+    if (!c->mur_on[f]) continue;
+    const int a = f / 2, hi = f & 1;
+    /* local index of the boundary line / its inner neighbour along a */
+    int b, in;
+    if (a == 2) { b = hi ? c->d.nz - 1 - c->d.k0 : 0 - c->d.k0; in = hi ? b - 1 : b + 1; }
+    else { b = hi ? dim[a] - 1 : 0; in = hi ? b - 1 : b + 1; }
+    const int p = (a + 1) % 3, q = (a + 2) % 3; /* in-face axes */
+    const float co = c->mur_c[f];
+    for (int t = 0; t < 2; ++t) {
+      const int comp = t == 0 ? p : q;
+      float* V = c->V[comp];
+      float* S = c->mur_st[f][t];
+      /* storage index: the two in-face axes in (slow, fast) = (larger axis id, smaller axis id) */
+      const int u = p < q ? p : q, v = p < q ? q : p; /* u fast, v slow */
+      for (int iv_ = 0; iv_ < dim[v]; ++iv_)
+        for (int iu = 0; iu < dim[u]; ++iu) {
+          size_t s = (size_t)iv_ * dim[u] + iu;
+          ptrdiff_t base = (ptrdiff_t)iu * st[u] + (ptrdiff_t)iv_ * st[v];
+          ptrdiff_t ob = base + (ptrdiff_t)b * st[a], oi = base + (ptrdiff_t)in * st[a];
+          if (mode == 0) S[s] = fmaf(-co, V[ob], V[oi]);
+          else if (mode == 1) S[s] = fmaf(co, V[oi], S[s]);
+          else V[ob] = S[s];
+        }
+    }
+  }
+}
+
+static void post_E(fdtd_ctx* c) {
+  mur_pass(c, 1);
+  mur_pass(c, 2);
+  /* soft voltage source, [EXT] Engine_Ext_Excitation::Apply2Voltages */
+  for (int e = 0; e < c->nsrc; ++e) {
+    int64_t t = c->step - c->src_delay[e];
+    if (t < 0 || t >= c->nsig) continue;
+    c->V[c->src_comp[e]][c->src_off[e]] += c->src_amp[e] * c->sig[t];
+  }
+}
+
+static void sample(fdtd_ctx* c, int kind) {
+  float** F = kind == FDTD_KIND_V ? c->V : c->I;
+  if (c->step < c->d.max_steps)
+    for (int p = 0; p < c->nprobe; ++p) {
+      probe_t* pr = &c->probe[p];
+      if (pr->kind != kind) continue;
+      double s = 0.0;
+      for (int e = 0; e < pr->n; ++e) s = fma((double)pr->w[e], (double)F[pr->comp[e]][pr->off[e]], s);
+      pr->series[c->step] = s;
+    }
+  if (c->nfreq && c->step % c->every == 0) {
+    int64_t smp = c->step / c->every;
+    if (smp < c->nsamples) {
+      const double* tw = (kind == FDTD_KIND_V ? c->tw_v : c->tw_i) + (size_t)smp * c->nfreq * 2;
+      for (int b = 0; b < c->nbox; ++b) {
+        dftbox_t* bx = &c->box[b];
+        if (bx->kind != kind || !bx->npts) continue;
+        const float* fld = F[bx->comp];
+        const int ni = bx->ohi[0] - bx->olo[0] + 1, nj = bx->ohi[1] - bx->olo[1] + 1, nkk = bx->ohi[2] - bx->olo[2] + 1;
+        for (int f = 0; f < c->nfreq; ++f) {
+          const double wr = tw[2 * f], wi = tw[2 * f + 1];
+          double* acc = bx->acc + (size_t)f * bx->npts * 2;
+#pragma omp parallel for collapse(2) schedule(static)
+          for (int kk = 0; kk < nkk; ++kk)
+            for (int jj = 0; jj < nj; ++jj) {
+              const float* src = fld + ((size_t)(bx->olo[2] - c->d.k0 + kk) * c->d.ny + bx->olo[1] + jj) * c->d.nx + bx->olo[0];
+              double* a = acc + ((size_t)kk * nj + jj) * ni * 2;
+              for (int ii_ = 0; ii_ < ni; ++ii_) {
+                double v = (double)src[ii_];
+                a[2 * ii_] = fma(v, wr, a[2 * ii_]);
+                a[2 * ii_ + 1] = fma(v, wi, a[2 * ii_ + 1]);
+              }
+            }
+        }
+      }
+    }
+  }
+}
+
+int fdtd_half_step(fdtd_ctx* c, int phase) {
+  if (!c) return FDTD_E_ARG;
+  if (!c->have_op) return fail(c, FDTD_E_STATE, "operator not set");
+  if (phase == FDTD_PHASE_E) {
+    mur_pass(c, 0);
+    update_E(c);
+    post_E(c);
+    sample(c, FDTD_KIND_V);
+  } else if (phase == FDTD_PHASE_H) {
+    update_H(c);
+    sample(c, FDTD_KIND_I);
+    c->step++;
+  } else return fail(c, FDTD_E_ARG, "bad phase");
+  return FDTD_OK;
+}
+
+int fdtd_run(fdtd_ctx* c, int nsteps) {
+  if (!c) return FDTD_E_ARG;
+  if (c->d.world > 1) return fail(c, FDTD_E_UNSUPPORTED, "oracle: use fdtd_half_step + fdtd_halo_* for world > 1");
+  for (int s = 0; s < nsteps; ++s) {
+    int r = fdtd_half_step(c, FDTD_PHASE_E);
+    if (r) return r;
+    r = fdtd_half_step(c, FDTD_PHASE_H);
+    if (r) return r;
+  }
+  return FDTD_OK;
+}
+
+int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
+  if (out) memset(out, 0, sizeof(*out));
+  return fdtd_run(c, nsteps);
+}
+
+int fdtd_get_step(fdtd_ctx* c, int64_t* step) {
+  if (!c || !step) return FDTD_E_ARG;
+  *step = c->step;
+  return FDTD_OK;
+}
+
+/* [EXT] openEMS energy estimate for the end criterion: sums of squares. */
+int fdtd_energy(fdtd_ctx* c, double sums[2]) {
+  if (!c || !sums) return FDTD_E_ARG;
+  double sv = 0.0, si = 0.0;
+  for (int n = 0; n < 3; ++n) {
+    const float *V = c->V[n], *I = c->I[n];
+#pragma omp parallel for reduction(+ : sv, si) schedule(static)
+    for (size_t p = 0; p < c->nloc; ++p) { sv += (double)V[p] * V[p]; si += (double)I[p] * I[p]; }
+  }
+  sums[0] = sv; sums[1] = si;
+  return FDTD_OK;
+}
+
+int fdtd_comm_unique_id(void* out128) { (void)out128; return fail(NULL, FDTD_E_UNSUPPORTED, "oracle has no RCCL transport"); }
+int fdtd_comm_init(fdtd_ctx* c, const void* uid) { (void)uid; return fail(c, FDTD_E_UNSUPPORTED, "oracle has no RCCL transport"); }
+
+int fdtd_halo_get(fdtd_ctx* c, int which, float* buf) {
+  if (!c || !buf) return FDTD_E_ARG;
+  size_t n = c->plane * sizeof(float);
+  if (which == FDTD_HALO_H_UP) {
+    memcpy(buf, c->I[0] + (size_t)(c->d.nk - 1) * c->plane, n);
+    memcpy(buf + c->plane, c->I[1] + (size_t)(c->d.nk - 1) * c->plane, n);
+  } else if (which == FDTD_HALO_E_DOWN) {
+    memcpy(buf, c->V[0], n);
+    memcpy(buf + c->plane, c->V[1], n);
+  } else return fail(c, FDTD_E_ARG, "bad halo id");
+  return FDTD_OK;
+}
+
+int fdtd_halo_put(fdtd_ctx* c, int which, const float* buf) {
+  if (!c || !buf) return FDTD_E_ARG;
+  size_t n = c->plane * sizeof(float);
+  if (which == FDTD_HALO_H_UP) { /* ghost plane below */
+    memcpy(c->I[0] - c->plane, buf, n);
+    memcpy(c->I[1] - c->plane, buf + c->plane, n);
+  } else if (which == FDTD_HALO_E_DOWN) { /* ghost plane above */
+    memcpy(c->V[0] + c->nloc, buf, n);
+    memcpy(c->V[1] + c->nloc, buf + c->plane, n);
+  } else return fail(c, FDTD_E_ARG, "bad halo id");
+  return FDTD_OK;
+}
+
+int fdtd_get_field(fdtd_ctx* c, int kind, int comp, float* out) {
+  if (!c || !out || comp < 0 || comp > 2) return FDTD_E_ARG;
+  memcpy(out, (kind == FDTD_KIND_V ? c->V : c->I)[comp], c->nloc * sizeof(float));
+  return FDTD_OK;
+}
+
+int fdtd_set_field(fdtd_ctx* c, int kind, int comp, const float* in) {
+  if (!c || !in || comp < 0 || comp > 2) return FDTD_E_ARG;
+  memcpy((kind == FDTD_KIND_V ? c->V : c->I)[comp], in, c->nloc * sizeof(float));
+  return FDTD_OK;
+}
+
+/* Radiation integral, restating what nf2ff.CalcNF2FF computes from the recorded surfaces
+ * (antenna_sim/solver_fdtd_openems_fixed.py:296); Balanis (12-10)..(12-12). */
+int fdtd_farfield(int device, int npts, const double* pos, const double* Js, const double* Ms,
+                  double kw, int nang, const double* theta, const double* phi, double* Eth, double* Eph) {
+  (void)device;
+  if (npts < 0 || nang < 0 || !pos || !Js || !Ms || !theta || !phi || !Eth || !Eph) return fail(NULL, FDTD_E_ARG, "bad farfield argument");
+  const double eta0 = 376.730313668;  /* sqrt(mu0/eps0) */
+  const double fac = kw / (4.0 * M_PI);
+#pragma omp parallel for schedule(static)
+  for (int a = 0; a < nang; ++a) {
+    const double st = sin(theta[a]), ct = cos(theta[a]), sp = sin(phi[a]), cp = cos(phi[a]);
+    const double rx = st * cp, ry = st * sp, rz = ct;
+    double N[3][2] = {{0}}, L[3][2] = {{0}};
+    for (int p = 0; p < npts; ++p) {
+      const double ph = kw * (rx * pos[3 * p] + ry * pos[3 * p + 1] + rz * pos[3 * p + 2]);
+      const double cr = cos(ph), ci = sin(ph);
+      for (int n = 0; n < 3; ++n) {
+        const double jr = Js[(3 * p + n) * 2], ji = Js[(3 * p + n) * 2 + 1];
+        const double mr = Ms[(3 * p + n) * 2], mi = Ms[(3 * p + n) * 2 + 1];
+        N[n][0] += jr * cr - ji * ci; N[n][1] += jr * ci + ji * cr;
+        L[n][0] += mr * cr - mi * ci; L[n][1] += mr * ci + mi * cr;
+      }
+    }
+    double Nth[2], Nph[2], Lth[2], Lph[2];
+    for (int z = 0; z < 2; ++z) {
+      Nth[z] = N[0][z] * ct * cp + N[1][z] * ct * sp - N[2][z] * st;
+      Nph[z] = -N[0][z] * sp + N[1][z] * cp;
+      Lth[z] = L[0][z] * ct * cp + L[1][z] * ct * sp - L[2][z] * st;
+      Lph[z] = -L[0][z] * sp + L[1][z] * cp;
+    }
+    /* Eth = -j*fac*(Lph + eta*Nth):  -j*(x+jy) = y - jx */
+    const double ar = Lph[0] + eta0 * Nth[0], ai = Lph[1] + eta0 * Nth[1];
+    Eth[2 * a] = fac * ai; Eth[2 * a + 1] = -fac * ar;
+    /* Eph = +j*fac*(Lth - eta*Nph):  j*(x+jy) = -y + jx */
+    const double br = Lth[0] - eta0 * Nph[0], bi = Lth[1] - eta0 * Nph[1];
+    Eph[2 * a] = -fac * bi; Eph[2 * a + 1] = fac * br;
+  }
+  return FDTD_OK;
+}
