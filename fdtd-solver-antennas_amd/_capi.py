@@ -106,7 +106,7 @@ def load_hip_library(lib_dir: Optional[str] = None) -> C.CDLL:
         raise RuntimeError(
             f"{HIP_LIB_NAME} not found at {path}: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the FDTD hot path.")
-    lib = bind(C.CDLL(path, mode=C.RTLD_GLOBAL))
+    lib = bind(C.CDLL(path))
     if lib_dir is None:
         _hip_lib = lib
     return lib

@@ -22,6 +22,6 @@ def seeded_fields(engine, seed=0, scale=1e-3):
 
 
 def rel_l2(a, b):
-    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    a = np.asarray(a); b = np.asarray(b)
     n = np.linalg.norm(b.ravel())
     return float(np.linalg.norm((a - b).ravel()) / (n if n > 0 else 1.0))
