@@ -1,0 +1,90 @@
+"""Rectilinear mesh generation: edge hints ("thirds rule") and graded smoothing.
+
+Restates what the reference asks of the external toolkit through
+``FDTD.AddEdges2Grid(dirs, properties, metal_edge_res)`` and ``mesh.SmoothMeshLines('all', res, 1.4)``
+(antenna_sim/solver_fdtd_openems_fixed.py:193,210,217): [EXT] openEMS automesh / CSXCAD
+SmoothMeshLines.  Their source is not available here, so line positions are NOT pinned against
+them; the invariants are (tests/test_mesher_cpu.py): every hint line is kept, no cell exceeds
+max_res, neighbouring cells differ by at most `ratio` wherever the hints allow it.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence
+import numpy as np
+
+
+def unique_lines(lines: Iterable[float], rel_tol: float = 1e-9) -> np.ndarray:
+    a = np.sort(np.asarray(list(lines), dtype=np.float64))
+    if a.size == 0:
+        return a
+    span = max(a[-1] - a[0], 1e-30)
+    keep = [a[0]]
+    for v in a[1:]:
+        if v - keep[-1] > rel_tol * span:
+            keep.append(v)
+    return np.array(keep)
+
+
+def mesh_hint_from_box(start: Sequence[float], stop: Sequence[float], dirs: Sequence[int],
+                       metal_edge_res: Optional[float] = None) -> List[Optional[List[float]]]:
+    """Hint lines for a box.  With metal_edge_res the metal edge is put 1/3 of a cell inside the
+    metal (lines at edge + res/3 inside and edge - 2 res/3 outside): the "thirds rule" that places
+    the singular edge field correctly on a Yee grid.  Degenerate extents give a single line."""
+    lo = np.minimum(start, stop).astype(float)
+    hi = np.maximum(start, stop).astype(float)
+    hints: List[Optional[List[float]]] = [None, None, None]
+    for a in range(3):
+        if a not in dirs:
+            continue
+        ext = hi[a] - lo[a]
+        if metal_edge_res is not None and ext > metal_edge_res:
+            r = float(metal_edge_res)
+            hints[a] = [lo[a] + r / 3.0, lo[a] - 2.0 * r / 3.0, hi[a] - r / 3.0, hi[a] + 2.0 * r / 3.0]
+        elif ext > 0:
+            hints[a] = [lo[a], hi[a]]
+        else:
+            hints[a] = [lo[a]]
+    return hints
+
+
+def _graded_fill(a: float, b: float, left: float, right: float, max_res: float, ratio: float) -> np.ndarray:
+    """Interior lines for the gap (a, b): cells grow by `ratio` from the neighbouring cell sizes
+    `left`/`right` towards max_res and are then scaled down uniformly to fit the gap exactly."""
+    gap = b - a
+    sl = min(max(left, 1e-30) * ratio, max_res)
+    sr = min(max(right, 1e-30) * ratio, max_res)
+    if gap <= min(max_res, max(sl, sr)) * (1 + 1e-9):
+        return np.empty(0)
+    ls, rs, tot = [], [], 0.0
+    while tot < gap * (1 - 1e-12):
+        if sl <= sr:
+            ls.append(sl); tot += sl; sl = min(sl * ratio, max_res)
+        else:
+            rs.append(sr); tot += sr; sr = min(sr * ratio, max_res)
+    cells = np.array(ls + rs[::-1])
+    if cells.size < 2:
+        return np.empty(0)
+    cells *= gap / cells.sum()
+    return a + np.cumsum(cells)[:-1]
+
+
+def smooth_mesh_lines(lines: Iterable[float], max_res: float, ratio: float = 1.5) -> np.ndarray:
+    """All hint lines, plus graded fill-in so that no cell is larger than max_res."""
+    out = unique_lines(lines)
+    if out.size < 2:
+        return out
+    max_res = float(max_res)
+    for _ in range(10 * out.size + 1000):
+        d = np.diff(out)
+        big = np.nonzero(d > max_res * (1 + 1e-9))[0]
+        if big.size == 0:
+            break
+        i = int(big[np.argmax(d[big])])
+        left = d[i - 1] if i > 0 else max_res
+        right = d[i + 1] if i + 1 < d.size else max_res
+        new = _graded_fill(out[i], out[i + 1], min(left, max_res), min(right, max_res), max_res, ratio)
+        if new.size == 0:   # cannot grade: split evenly
+            n = int(np.ceil(d[i] / max_res))
+            new = out[i] + d[i] * np.arange(1, n) / n
+        out = np.concatenate([out[:i + 1], new, out[i + 1:]])
+    return out

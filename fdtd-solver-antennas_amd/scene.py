@@ -24,6 +24,7 @@ class Box:
     start: Tuple[float, float, float]
     stop: Tuple[float, float, float]
     priority: int = 0
+    matrix: Optional[np.ndarray] = None   # 4x4 local->world (drawing units), None = identity
 
 
 @dataclass
@@ -117,11 +118,41 @@ def _tol(grid: RectGrid) -> float:
     return 1e-6 * min(float(np.min(np.diff(l))) for l in grid.lines)
 
 
-def _index_range(lines: np.ndarray, a: float, b: float, tol: float):
+def _index_range(lines: np.ndarray, a: float, b: float, tol: float):  # kept for tools/tests
     """Node indices whose coordinate lies in [min(a,b), max(a,b)] (with tolerance)."""
     lo, hi = (a, b) if a <= b else (b, a)
     idx = np.nonzero((lines >= lo - tol) & (lines <= hi + tol))[0]
     return (int(idx[0]), int(idx[-1])) if idx.size else (0, -1)
+
+
+def _inside_mask(bx: Box, u: float, tol: float, coords: Sequence[np.ndarray]):
+    """Boolean block over the sub-grid of points `coords` (one 1-D array per axis, metres) that lie
+    inside the (possibly rotated/translated) box.  Returns (mask[z][y][x], index offsets) or None."""
+    lo = np.minimum(bx.start, bx.stop) * u
+    hi = np.maximum(bx.start, bx.stop) * u
+    if bx.matrix is None or np.allclose(bx.matrix, np.eye(4)):
+        sel = [np.nonzero((c >= lo[a] - tol) & (c <= hi[a] + tol))[0] for a, c in enumerate(coords)]
+        if any(s_.size == 0 for s_ in sel):
+            return None
+        off = [int(s_[0]) for s_ in sel]
+        shape = [int(s_[-1]) - int(s_[0]) + 1 for s_ in sel]
+        return np.ones((shape[2], shape[1], shape[0]), bool), off
+    M = np.array(bx.matrix, dtype=float)
+    M[:3, 3] *= u
+    corners = np.array([[x, y, z, 1.0] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+    w = (M @ corners.T).T[:, :3]
+    sel = [np.nonzero((c >= w[:, a].min() - tol) & (c <= w[:, a].max() + tol))[0] for a, c in enumerate(coords)]
+    if any(s_.size == 0 for s_ in sel):
+        return None
+    off = [int(s_[0]) for s_ in sel]
+    sub = [coords[a][sel[a][0]:sel[a][-1] + 1] for a in range(3)]
+    Z, Y, X = np.meshgrid(sub[2], sub[1], sub[0], indexing="ij")
+    Minv = np.linalg.inv(M)
+    P = np.stack([X, Y, Z, np.ones_like(X)], axis=-1) @ Minv.T
+    mask = np.ones(X.shape, bool)
+    for a in range(3):
+        mask &= (P[..., a] >= lo[a] - tol) & (P[..., a] <= hi[a] + tol)
+    return mask, off
 
 
 def voxelize(scene: Scene, grid: RectGrid) -> VoxelScene:
@@ -131,32 +162,34 @@ def voxelize(scene: Scene, grid: RectGrid) -> VoxelScene:
     eps = np.ones((nz - 1, ny - 1, nx - 1))
     kap = np.zeros_like(eps)
     prio = np.full(eps.shape, -(1 << 30), dtype=np.int64)
-    cx, cy, cz = (grid.centers(a) for a in range(3))
+    centers = [grid.centers(a) for a in range(3)]
     for mat in scene.materials:
         for bx in mat.boxes:
-            sel = []
-            for c, a in ((cx, 0), (cy, 1), (cz, 2)):
-                lo, hi = sorted((bx.start[a] * u, bx.stop[a] * u))
-                sel.append(np.nonzero((c > lo - tol) & (c < hi + tol))[0])
-            if any(s.size == 0 for s in sel):
+            r = _inside_mask(bx, u, -tol, centers)     # strict: a cell centre on the surface is outside
+            if r is None:
                 continue
-            sx, sy, sz = (slice(int(s[0]), int(s[-1]) + 1) for s in sel)
-            win = prio[sz, sy, sx] <= bx.priority
-            e = eps[sz, sy, sx]; k = kap[sz, sy, sx]; p = prio[sz, sy, sx]
+            mask, off = r
+            sl = tuple(slice(off[a], off[a] + mask.shape[2 - a]) for a in (2, 1, 0))
+            win = mask & (prio[sl] <= bx.priority)
+            e = eps[sl]; k = kap[sl]; p = prio[sl]
             e[win] = mat.eps_r; k[win] = mat.kappa; p[win] = bx.priority
     pec = np.zeros((3, nz, ny, nx), dtype=bool)
     for met in scene.metals:
         for bx in met.boxes:
-            r = [_index_range(grid.lines[a], bx.start[a] * u, bx.stop[a] * u, tol) for a in range(3)]
-            if any(hi < lo for lo, hi in r):
+            r = _inside_mask(bx, u, tol, grid.lines)
+            if r is None:
                 continue
+            node, off = r
             for c in range(3):
-                rr = list(r)
-                lo, hi = rr[c]
-                if hi - lo < 1:
-                    continue          # no full edge of this direction inside the box
-                rr[c] = (lo, hi - 1)  # edge i spans nodes i..i+1
-                pec[c, rr[2][0]:rr[2][1] + 1, rr[1][0]:rr[1][1] + 1, rr[0][0]:rr[0][1] + 1] = True
+                npa = 2 - c                                   # numpy axis of direction c
+                if node.shape[npa] < 2:
+                    continue
+                a = [slice(None)] * 3; b = [slice(None)] * 3
+                a[npa] = slice(0, -1); b[npa] = slice(1, None)
+                edge = node[tuple(a)] & node[tuple(b)]        # both end nodes inside
+                sl = [slice(off[2], off[2] + edge.shape[0]), slice(off[1], off[1] + edge.shape[1]),
+                      slice(off[0], off[0] + edge.shape[2])]
+                pec[c][tuple(sl)] |= edge
     ports = [_port_on_grid(p, grid, u) for p in scene.ports]
     return VoxelScene(eps, kap, pec, ports)
 
