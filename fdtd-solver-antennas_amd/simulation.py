@@ -112,6 +112,7 @@ class Simulation:
             self.dft_nsamples = self.nr_ts // self.dft_every + 1
         self.engine: Optional[Engine] = None
         self.lib = None
+        self.external_transport = None     # distributed.SlabComm when halos travel through the host
         self._port_probe_ids = []
         self._nf_ids = []
 
@@ -168,7 +169,10 @@ class Simulation:
         done = e.step
         while done < total:
             n = min(check_every, total - done)
-            e.run(n)
+            if self.external_transport is not None:
+                self.external_transport.run_steps(e, n)
+            else:
+                e.run(n)
             done += n
             sv, si = e.energy()
             s = np.array([sv, si])

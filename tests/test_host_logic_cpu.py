@@ -1,0 +1,132 @@
+"""Host-side logic (no GPU): mesher invariants, operator forms, slab partitioning, CPML slab tables,
+rotated-box voxelisation, and the end-to-end plugin path with the oracle injected as the engine."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+from helpers import patch_sim
+
+
+def test_smooth_mesh_lines_invariants():
+    m = pkg("mesher")
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        hints = np.concatenate([[-100.0, 100.0], rng.uniform(-60, 60, 8), [0.0, 0.4, 0.8, 1.2, 1.6]])
+        out = m.smooth_mesh_lines(hints, 4.08, 1.4)
+        d = np.diff(out)
+        assert np.all(d > 0) and d.max() <= 4.08 * (1 + 1e-9)
+        for h in hints:
+            assert np.min(np.abs(out - h)) < 1e-9          # every hint line survives
+        # grading: away from forced hint lines the neighbour ratio stays within `ratio`
+        ratio = np.maximum(d[1:] / d[:-1], d[:-1] / d[1:])
+        forced = np.array([np.min(np.abs(hints - x)) < 1e-9 for x in out])
+        free = ~(forced[1:-1])
+        assert np.all(ratio[free] <= 1.4 * 1.02)
+
+
+def test_thirds_rule_hint():
+    m = pkg("mesher")
+    h = m.mesh_hint_from_box([-18.0, -14.0, 1.6], [18.0, 14.0, 1.6], [0, 1], metal_edge_res=2.1)
+    assert h[2] is None
+    assert sorted(h[0]) == pytest.approx(sorted([-18 + 0.7, -18 - 1.4, 18 - 0.7, 18 + 1.4]))
+    assert m.mesh_hint_from_box([-6, 0, 0], [-6, 0, 1.6], [0, 1], None)[:2] == [[-6.0], [0.0]]
+
+
+def test_slab_range_partitions():
+    sr = pkg("simulation").slab_range
+    for nz in (40, 60, 61, 120, 128):
+        for w in (1, 2, 3, 4, 8):
+            parts = [sr(nz, w, r) for r in range(w)]
+            assert parts[0][0] == 0 and sum(nk for _, nk in parts) == nz
+            for (a, n), (b, _) in zip(parts[:-1], parts[1:]):
+                assert a + n == b
+            assert max(nk for _, nk in parts) - min(nk for _, nk in parts) <= 1
+
+
+def test_cpml_slab_tables_are_end_anchored():
+    s = patch_sim(40, 40, 60, cpml_cells=10, nr_ts=10, nf2ff=False)
+    n_full = None
+    for world in (1, 2, 4, 8):
+        tot = 0
+        for r in range(world):
+            k0, nk = pkg("simulation").slab_range(60, world, r)
+            sx, sy, sz, nsx, nsy, nsz, coef = s.cpml.for_slab(k0, nk)
+            assert coef.size == 6 * (40 + 40 + nk)
+            own = sz[sz >= 0]
+            assert np.array_equal(own, np.arange(nsz))         # compact local numbering
+            lo = 0
+            while lo < nk and sz[lo] == lo:
+                lo += 1
+            hi = lo
+            while hi < nk and sz[hi] < 0:
+                hi += 1
+            assert np.array_equal(sz[hi:], lo + np.arange(nk - hi))  # [0,lo) and [hi,nk) — what the kernels assume
+            tot += nsz
+        n_full = tot if n_full is None else n_full
+        assert tot == n_full
+
+
+def test_operator_class_and_raw_forms_agree(oracle_lib):
+    """The compressed operator (class bytes + 1-D tables) expands to exactly the raw arrays."""
+    s = patch_sim(36, 34, 30, nr_ts=60, nf2ff=False)
+    cls = s.op.classes()
+    assert cls is not None and cls[1].size <= 256
+    res = []
+    for use in (True, False):
+        s2 = patch_sim(36, 34, 30, nr_ts=60, nf2ff=False, use_classes=use)
+        e = s2.build(oracle_lib)
+        e.run(60)
+        res.append(e.fields())
+        assert s2.operator_form == ("classes" if use else "raw")
+    assert np.array_equal(res[0], res[1])
+
+
+def test_rotated_box_voxelisation():
+    sc, g = pkg("scene"), pkg("grid")
+    grid = g.RectGrid(np.linspace(-20e-3, 20e-3, 41), np.linspace(-20e-3, 20e-3, 41), np.linspace(-10e-3, 10e-3, 21))
+    M = np.eye(4)
+    ang = np.deg2rad(90.0)
+    M[:3, :3] = [[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]]
+    M[:3, 3] = [2.0, 0.0, 1.0]
+    a, b = sc.Scene(), sc.Scene()
+    a.add_metal("m").boxes.append(sc.Box((-10.0, -4.0, 0.0), (10.0, 4.0, 0.0), 10, M))
+    b.add_metal("m").add_box([-4.0 + 2.0, -10.0, 1.0], [4.0 + 2.0, 10.0, 1.0], 10)   # the same sheet, axis aligned
+    va, vb = sc.voxelize(a, grid), sc.voxelize(b, grid)
+    assert va.pec.sum() > 0 and np.array_equal(va.pec, vb.pec)
+    a.add_material("d", 4.3, 0.01).boxes.append(sc.Box((-10.0, -4.0, -1.0), (10.0, 4.0, 0.0), 0, M))
+    b.add_material("d", 4.3, 0.01).add_box([-2.0, -10.0, 0.0], [6.0, 10.0, 1.0], 0)
+    va, vb = sc.voxelize(a, grid), sc.voxelize(b, grid)
+    assert (va.eps_r > 1).sum() > 0 and np.array_equal(va.eps_r, vb.eps_r)
+    # a 30-degree sheet is a staircase with about the same area
+    ang = np.deg2rad(30.0)
+    M2 = np.eye(4)
+    M2[:3, :3] = [[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]]
+    c = sc.Scene()
+    c.add_metal("m").boxes.append(sc.Box((-10.0, -4.0, 0.0), (10.0, 4.0, 0.0), 10, M2))
+    vc = sc.voxelize(c, grid)
+    ref = sc.voxelize(b, grid).pec.sum()
+    assert 0.8 * ref < vc.pec.sum() < 1.2 * ref
+
+
+def test_fixed_scene_end_to_end_with_oracle_engine(oracle_lib, tmp_path):
+    """PatchAntennaParams in -> OpenEMSResult-shaped object out, through the plugin surface, with the
+    oracle standing in for the GPU library (test hook `_engine_lib`).  Physics bands:
+    this variant puts W = 37.6 mm on the resonant axis, so the S11 dip sits near 1.9 GHz."""
+    s = pkg("solver_fdtd_hip")
+    P = pkg("params").PatchAntennaParams
+    p = P.from_user_units(frequency_ghz=2.45, er=4.3, h_mm=1.6, loss_tangent=0.02)
+    prep = s.prepare_hip_patch_fixed(p, work_dir=str(tmp_path / "run"), _engine_lib=oracle_lib)
+    assert prep.ok, prep.message
+    prep.FDTD.NrTS = 9000
+    r = s.run_prepared_hip(prep, frequency_hz=2.45e9, verbose=0)
+    assert r.ok, r.message
+    assert r.is_dBi and r.intensity.shape == (90, 2)
+    assert r.theta.shape == (90,) and abs(r.theta[1] - np.deg2rad(2.0)) < 1e-12 and np.allclose(r.phi, [0, np.pi / 2])
+    assert abs(r.intensity.max() - 10 * np.log10(r.Dmax)) < 1e-9
+    assert 4.0 < 10 * np.log10(r.Dmax) < 9.0                     # patch-antenna directivity band
+    assert np.argmax(r.intensity[:, 0]) < 20                      # main lobe near broadside
+    k = int(np.argmin(r.s11_dB))
+    assert 1.75e9 < r.freq[k] < 2.05e9 and r.s11_dB[k] < -6.0
+    assert r.stats["cells"] > 1e5 and r.stats["steps"] == 9000
+    import os
+    assert os.path.isfile(os.path.join(r.sim_path, "fdtd_hip_run.json"))

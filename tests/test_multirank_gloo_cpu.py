@@ -1,0 +1,64 @@
+"""N > 1 on CPU: two processes, gloo, z-slab decomposition with the host halo transport, the oracle
+standing in as the per-rank engine.  The two-slab run must reproduce the single-slab run bit for bit
+(fields), and the rank-summed port series / NF2FF surfaces / energy must match."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pkg
+from helpers import patch_sim
+
+SHAPE = (40, 38, 36)
+STEPS = 120
+
+
+def _worker(rank, world, port, out_dir):
+    import ctypes
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = pkg("_capi").bind(ctypes.CDLL(os.path.join(ROOT, "oracle", "libfdtd_oracle.so")))
+    s = patch_sim(*SHAPE, cpml_cells=8, nr_ts=STEPS)
+    e = s.build(lib, rank=rank, world=world)
+    comm = pkg("distributed").SlabComm(transport="host")
+    comm.attach(s)
+    assert s.external_transport is comm
+    st = s.run(check_every=40, allreduce=comm.allreduce)
+    u, i = s.port_series(comm.allreduce)[0]
+    boxes = s.nf2ff_boxes(comm.allreduce)
+    sv, si = e.energy()
+    en = comm.allreduce(np.array([sv, si]))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), fields=e.fields(), u=u, i=i, k0=e.k0, nk=e.nk, en=en,
+             steps=st.steps, **{f"box{n}": b for n, b in enumerate(boxes)})
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one(oracle_lib, tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    s = patch_sim(*SHAPE, cpml_cells=8, nr_ts=STEPS)
+    e = s.build(oracle_lib)
+    e.run(STEPS)
+    r = [np.load(tmp_path / f"rank{q}.npz") for q in range(2)]
+    assert int(r[0]["k0"]) == 0 and int(r[0]["nk"]) + int(r[1]["nk"]) == SHAPE[2]
+    assert int(r[0]["steps"]) == STEPS
+    both = np.concatenate([r[0]["fields"], r[1]["fields"]], axis=2)
+    ref = e.fields()
+    assert np.abs(ref).max() > 0
+    assert np.array_equal(both.view(np.uint32), ref.view(np.uint32))
+    u, i = s.port_series()[0]
+    assert np.allclose(r[0]["u"], u, rtol=1e-12, atol=0) and np.allclose(r[1]["i"], i, rtol=1e-12, atol=1e-300)
+    for n, b in enumerate(s.nf2ff_boxes()):
+        assert np.allclose(r[0][f"box{n}"], b, rtol=1e-12, atol=1e-30)
+        assert np.allclose(r[1][f"box{n}"], b, rtol=1e-12, atol=1e-30)
+    sv, si = e.energy()
+    assert np.allclose(r[0]["en"], [sv, si], rtol=1e-12)
