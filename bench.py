@@ -145,15 +145,29 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: min(affinity mask, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(capi, simm, w, vox, args):
     """The oracle (plain-C restatement, OpenMP) on a bounded sample of the same workload."""
     import numpy as np
     so = os.path.join(ROOT, "oracle", "libfdtd_oracle.so")
     if not os.path.isfile(so):
         return None
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     ora = capi.bind(ctypes.CDLL(so))
+    ora.fdtd_oracle_set_threads(cores)
+    cores = int(ora.fdtd_oracle_get_threads())
     steps = args.cpu_steps or max(10, int(2.0e9 / w.grid.ncells))   # ~2e9 cell-steps: 10-30 s of CPU work
     sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=args.cpml_cells,
                           nr_ts=steps + 16, nf2ff_freqs=[w.f0])

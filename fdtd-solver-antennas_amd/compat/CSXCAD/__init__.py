@@ -1,6 +1,11 @@
 """`from CSXCAD import ContinuousStructure` shim (antenna_sim/solver_fdtd_openems_fixed.py:131)."""
 import importlib as _il
+import os as _os
+import sys as _sys
 
+_root = _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))))
+if _root not in _sys.path:
+    _sys.path.insert(0, _root)
 _api = _il.import_module("fdtd-solver-antennas_amd.openems_api")
 ContinuousStructure = _api.ContinuousStructure
 

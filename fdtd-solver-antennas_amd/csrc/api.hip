@@ -96,8 +96,6 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
     CK(hipMalloc(&c->fieldbase[n], fbytes));
     CK(hipMemset(c->fieldbase[n], 0, fbytes));
   }
-  CK(hipMalloc(&c->d_step, sizeof(long long)));
-  CK(hipMemset(c->d_step, 0, sizeof(long long)));
   CK(hipMalloc(&c->d_energy, 2 * sizeof(double)));
   CK(hipMalloc(&c->d_probe, sizeof(DevProbe) * FDTD_MAX_PROBES));
   CK(hipMalloc(&c->d_box, sizeof(DevBox) * FDTD_MAX_BOXES));
@@ -117,6 +115,17 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   }
   for (int a = 0; a < 3; ++a) { p.pml_lo[a] = 0; p.pml_hi[a] = 1 << 30; p.pml_hi_slot[a] = 0; p.nslot[a] = 0; }
   choose_tiling(c);
+  {
+    const size_t nflag = (size_t)d->nk * p.nstrips;
+    if (hipMalloc(&c->src_flag, nflag) != hipSuccess || hipMemset(c->src_flag, 0, nflag) != hipSuccess) {
+      fdtd_fail(nullptr, FDTD_E_NOMEM, "source flags");
+      fdtd_destroy(c);
+      return FDTD_E_NOMEM;
+    }
+  }
+  p.src_flag = c->src_flag; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
+  p.sig = c->sig; p.nsig = 0;
+  p.probes = c->d_probe; p.nprobe = 0; p.max_steps = d->max_steps;
   *out = c;
   return FDTD_OK;
 }
@@ -138,7 +147,7 @@ void fdtd_destroy(fdtd_ctx* c) {
   }
   for (int b = 0; b < c->nbox; ++b) hipFree(c->box[b].acc);
   hipFree(c->d_probe); hipFree(c->d_box); hipFree(c->tw_v); hipFree(c->tw_i);
-  hipFree(c->d_step); hipFree(c->d_energy);
+  hipFree(c->d_energy); hipFree(c->src_flag);
   if (c->ev_E) hipEventDestroy(c->ev_E);
   if (c->ev_H) hipEventDestroy(c->ev_H);
   if (c->ev_haloE) hipEventDestroy(c->ev_haloE);
@@ -177,10 +186,45 @@ int fdtd_set_operator_classes(fdtd_ctx* c, const uint8_t* ecls, int ncls, const 
     if (ecls[q] >= ncls) return fdtd_fail(c, FDTD_E_ARG, "class %d >= ncls %d", (int)ecls[q], ncls);
   if (!c->ecls) HIPCK(c, hipMalloc(&c->ecls, n));
   HIPCK(c, hipMemset(c->ecls, 0, n));
-  HIPCK(c, upload_rows(c->ecls, P, ecls, nx, (size_t)3 * nk * ny));
-  std::vector<float2> lut(256, make_float2(0.f, 0.f));
-  for (int q = 0; q < ncls; ++q) lut[q] = make_float2(cls_vv[q], cls_m[q]);
-  HIPCK(c, hipMemcpy(c->lut, lut.data(), 256 * sizeof(float2), hipMemcpyHostToDevice));
+  // One byte per CELL when the scene has <= 256 distinct (cx, cy, cz) class triples (1 B instead of
+  // 3 B per cell-step of coefficient traffic); otherwise one byte per edge.
+  {
+    const size_t ncell = (size_t)nk * ny * nx;
+    std::vector<int> slot(1 << 24, -1);
+    std::vector<uint32_t> triples;
+    std::vector<uint8_t> packed(ncell);
+    bool ok = true;
+    for (size_t q = 0; q < ncell && ok; ++q) {
+      const uint32_t key = (uint32_t)ecls[q] | ((uint32_t)ecls[ncell + q] << 8) | ((uint32_t)ecls[2 * ncell + q] << 16);
+      int sidx = slot[key];
+      if (sidx < 0) {
+        if (triples.size() == 256) { ok = false; break; }
+        sidx = slot[key] = (int)triples.size();
+        triples.push_back(key);
+      }
+      packed[q] = (uint8_t)sidx;
+    }
+    c->packed_op = ok;
+    if (ok) {
+      HIPCK(c, upload_rows(c->ecls, P, packed.data(), nx, (size_t)nk * ny));
+      std::vector<float2> lut3(768, make_float2(0.f, 0.f));
+      for (size_t t = 0; t < triples.size(); ++t)
+        for (int comp = 0; comp < 3; ++comp) {
+          const int cl = (triples[t] >> (8 * comp)) & 0xFF;
+          lut3[3 * t + comp] = make_float2(cls_vv[cl], cls_m[cl]);
+        }
+      hipFree(c->lut); c->lut = nullptr;
+      HIPCK(c, hipMalloc(&c->lut, 768 * sizeof(float2)));
+      HIPCK(c, hipMemcpy(c->lut, lut3.data(), 768 * sizeof(float2), hipMemcpyHostToDevice));
+    } else {
+      HIPCK(c, upload_rows(c->ecls, P, ecls, nx, (size_t)3 * nk * ny));
+      std::vector<float2> lut(256, make_float2(0.f, 0.f));
+      for (int q = 0; q < ncls; ++q) lut[q] = make_float2(cls_vv[q], cls_m[q]);
+      hipFree(c->lut); c->lut = nullptr;
+      HIPCK(c, hipMalloc(&c->lut, 256 * sizeof(float2)));
+      HIPCK(c, hipMemcpy(c->lut, lut.data(), 256 * sizeof(float2), hipMemcpyHostToDevice));
+    }
+  }
   // metric tables: per (E|H, comp): x (padded to P, zeros), y, z — each segment 4-float aligned
   auto al4 = [](int v) { return (v + 3) / 4 * 4; };
   const int seg = P + al4(ny) + al4(nk);
@@ -303,6 +347,7 @@ int fdtd_set_signal(fdtd_ctx* c, const float* sig, int n) {
   HIPCK(c, hipMalloc(&c->sig, n * sizeof(float)));
   HIPCK(c, hipMemcpy(c->sig, sig, n * sizeof(float), hipMemcpyHostToDevice));
   c->nsig = n;
+  c->p.sig = c->sig; c->p.nsig = n;
   return FDTD_OK;
 }
 
@@ -332,6 +377,16 @@ int fdtd_add_source(fdtd_ctx* c, int n, const int64_t* idx, const int8_t* comp, 
   HIPCK(c, to_device(&c->src_comp, c->h_src_comp));
   HIPCK(c, to_device(&c->src_amp, c->h_src_amp));
   HIPCK(c, to_device(&c->src_delay, c->h_src_delay));
+  {
+    std::vector<uint8_t> flag((size_t)c->d.nk * c->p.nstrips, 0);
+    for (int off : c->h_src_off) {
+      const int k = off / c->plane, j = (off - k * c->plane) / c->P;
+      flag[(size_t)k * c->p.nstrips + j / c->p.tys] = 1;
+    }
+    HIPCK(c, hipMemcpy(c->src_flag, flag.data(), flag.size(), hipMemcpyHostToDevice));
+  }
+  c->p.nsrc = c->nsrc; c->p.src_off = c->src_off; c->p.src_comp = c->src_comp; c->p.src_amp = c->src_amp;
+  c->p.src_delay = c->src_delay;
   return FDTD_OK;
 }
 
@@ -360,6 +415,7 @@ int fdtd_add_probe(fdtd_ctx* c, int kind, int n, const int64_t* idx, const int8_
   if (id_out) *id_out = c->nprobe;
   c->nprobe++;
   HIPCK(c, hipMemcpy(c->d_probe, c->probe, sizeof(DevProbe) * FDTD_MAX_PROBES, hipMemcpyHostToDevice));
+  c->p.probes = c->d_probe; c->p.nprobe = c->nprobe;
   return FDTD_OK;
 }
 
@@ -482,45 +538,55 @@ struct ProfEvents {
   hipEvent_t t0 = nullptr, t1 = nullptr;
 };
 
+// One leapfrog step = two main launches.  Without Mur faces the soft sources are injected inside update_E
+// and the probes are sampled by one extra block of the main kernels (update_H(n): V-probes of step n;
+// update_E(n+1): I-probes of step n; the last step's I-probes are flushed at the end of the call).
 static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   const int nk = c->d.nk;
   const bool multi = c->d.world > 1;
   if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_comm_init (RCCL) or drive fdtd_half_step + fdtd_halo_*");
+  const bool fused = !c->any_mur;
   hipStream_t s = c->stream;
   for (int n = 0; n < nsteps; ++n) {
+    const long long step = c->step;
     // ---- E half-step: interior planes first, plane 0 (needs the H ghost from below) last ----
     launch_mur(c, 0, s);
     if (pe) HIPCK(c, hipEventRecord(pe->e0[n], s));
     if (multi && c->d.rank > 0) {
-      launch_update_E(c, 1, nk, s);
+      launch_update_E(c, 1, nk, step, fused, true, s);
       if (pe) HIPCK(c, hipEventRecord(pe->e1[n], s));
       if (c->haloH_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloH, 0)); c->haloH_pending = false; }
-      launch_update_E(c, 0, 1, s);
+      launch_update_E(c, 0, 1, step, fused, false, s);
     } else {
-      launch_update_E(c, 0, nk, s);
+      launch_update_E(c, 0, nk, step, fused, true, s);
       if (pe) HIPCK(c, hipEventRecord(pe->e1[n], s));
       if (c->haloH_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloH, 0)); c->haloH_pending = false; }
     }
-    launch_mur(c, 1, s);
-    launch_mur(c, 2, s);
-    launch_post(c, FDTD_KIND_V, s);
+    if (!fused) {
+      launch_mur(c, 1, s);
+      launch_mur(c, 2, s);
+      launch_post(c, FDTD_KIND_V, step, true, s);
+    }
+    launch_dft(c, FDTD_KIND_V, step, s);
     if (multi) { int r = exchange(c, FDTD_HALO_E_DOWN); if (r) return r; }
     // ---- H half-step: all planes but the top one overlap the E halo; the top plane goes last ----
     if (pe) HIPCK(c, hipEventRecord(pe->h0[n], s));
     if (multi && c->d.rank < c->d.world - 1) {
-      launch_update_H(c, 0, nk - 1, s);
+      launch_update_H(c, 0, nk - 1, step, fused, s);
       if (pe) HIPCK(c, hipEventRecord(pe->h1[n], s));
       if (c->haloE_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloE, 0)); c->haloE_pending = false; }
-      launch_update_H(c, nk - 1, nk, s);
+      launch_update_H(c, nk - 1, nk, step, false, s);
     } else {
-      launch_update_H(c, 0, nk, s);
+      launch_update_H(c, 0, nk, step, fused, s);
       if (pe) HIPCK(c, hipEventRecord(pe->h1[n], s));
       if (c->haloE_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloE, 0)); c->haloE_pending = false; }
     }
-    launch_post(c, FDTD_KIND_I, s);
+    if (!fused) launch_post(c, FDTD_KIND_I, step, false, s);
+    launch_dft(c, FDTD_KIND_I, step, s);
     if (multi) { int r = exchange(c, FDTD_HALO_H_UP); if (r) return r; }
     c->step++;
   }
+  if (fused && nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, s);   // flush the last step's I-probes
   HIPCK(c, hipGetLastError());
   return FDTD_OK;
 }
@@ -592,13 +658,15 @@ int fdtd_half_step(fdtd_ctx* c, int phase) {
   hipStream_t s = c->stream;
   if (phase == FDTD_PHASE_E) {
     launch_mur(c, 0, s);
-    launch_update_E(c, 0, c->d.nk, s);
+    launch_update_E(c, 0, c->d.nk, c->step, false, false, s);
     launch_mur(c, 1, s);
     launch_mur(c, 2, s);
-    launch_post(c, FDTD_KIND_V, s);
+    launch_post(c, FDTD_KIND_V, c->step, true, s);
+    launch_dft(c, FDTD_KIND_V, c->step, s);
   } else if (phase == FDTD_PHASE_H) {
-    launch_update_H(c, 0, c->d.nk, s);
-    launch_post(c, FDTD_KIND_I, s);
+    launch_update_H(c, 0, c->d.nk, c->step, false, s);
+    launch_post(c, FDTD_KIND_I, c->step, false, s);
+    launch_dft(c, FDTD_KIND_I, c->step, s);
     c->step++;
   } else return fdtd_fail(c, FDTD_E_ARG, "bad phase");
   HIPCK(c, hipGetLastError());

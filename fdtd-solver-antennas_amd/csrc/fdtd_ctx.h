@@ -24,8 +24,8 @@ struct DevParams {
   float* I[3];
   // operator: raw arrays [3][nk*plane] or class bytes + LUT + 1-D metric tables
   const float* vv; const float* vi; const float* ii; const float* iv;
-  const uint8_t* ecls;
-  const float2* lut;         // [256] (vv, m)
+  const uint8_t* ecls;       // class mode: [3][nloc] one byte per edge; packed mode: [nloc] one byte per cell
+  const float2* lut;         // class mode: [256] (vv, m); packed mode: [256][3] (vv, m) per component
   const float* emet[3][3];   // [comp][axis], x tables padded to P with zeros
   const float* hmet[3][3];
   // CPML: index q along axis a is in a layer iff q < pml_lo[a] (slot q) or q >= pml_hi[a]
@@ -36,6 +36,11 @@ struct DevParams {
   float* psiH[3][2];
   // launch tiling: a block = 256 threads = 1024 consecutive x-cells of one strip of `tys` rows in one plane
   int tys, nbs, nstrips;
+  // fused soft sources (update_E) and probes (extra block of update_E / update_H)
+  const uint8_t* src_flag;   // [nk][nstrips]: strip-plane contains a source edge
+  int nsrc; const int* src_off; const int8_t* src_comp; const float* src_amp; const int* src_delay;
+  const float* sig; int nsig;
+  const struct DevProbe* probes; int nprobe; int max_steps;
 };
 
 struct DevProbe { int kind, n; const int* off; const int8_t* comp; const float* w; double* series; };
@@ -53,7 +58,8 @@ struct fdtd_ctx {
   uint8_t* ecls = nullptr;
   float2* lut = nullptr;
   float* met = nullptr;          // packed metric tables
-  bool have_op = false, raw_op = false;
+  bool have_op = false, raw_op = false, packed_op = false;
+  uint8_t* src_flag = nullptr;
   // cpml
   bool have_cpml = false;
   float* cpcoef = nullptr;
@@ -73,7 +79,6 @@ struct fdtd_ctx {
   int32_t box_lo[FDTD_MAX_BOXES][3] = {}, box_hi[FDTD_MAX_BOXES][3] = {};
   long box_maxpts[2] = {0, 0};
   // stepping
-  long long* d_step = nullptr;   // device step counter (kernels index signal/probes with it)
   int64_t step = 0;
   double* d_energy = nullptr;
   hipStream_t stream = nullptr, comm_stream = nullptr;
@@ -93,9 +98,12 @@ int fdtd_fail(fdtd_ctx* c, int code, const char* fmt, ...);
   } while (0)
 
 // kernels.hip
-void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, hipStream_t s);
-void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, hipStream_t s);
+// `fused`: sources injected inside update_E; `probe_block`: one extra block samples the probes
+// (update_E: I-probes of step-1, update_H: V-probes of step) so a step is exactly two launches.
+void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool fused, bool probe_block, hipStream_t s);
+void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s);
 void launch_mur(fdtd_ctx* c, int mode, hipStream_t s);
-void launch_post(fdtd_ctx* c, int kind, hipStream_t s);   // sources (E) + probes + dft + step++ (H)
+void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_t s);   // stand-alone sources + probes
+void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);
 void launch_energy(fdtd_ctx* c, hipStream_t s);
 void choose_tiling(fdtd_ctx* c);

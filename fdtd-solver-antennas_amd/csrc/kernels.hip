@@ -2,7 +2,8 @@
 //
 //   K1 k_update_E   V <- vv*V + vi*curl(I)   + fused CPML psi update      
 //   K2 k_update_H   I <- ii*I + iv*curl(V)   + fused CPML psi update      (N2, N7)
-//   K3 k_post       soft source injection, V/I probe sampling, step++     (N4, N8)
+//   K3 sources/probes: fused into K1/K2 (source add inside update_E, probes in one extra block);
+//      k_post is the stand-alone form used with Mur boundaries and by fdtd_half_step     (N4, N8)
 //   K4 k_mur        first-order Mur pre / post / apply on the six faces   (N6)
 //   K6 k_dft        running DFT of field boxes (NF2FF surfaces)           (N9)
 //   K8 k_energy     sum V^2, sum I^2                                      (N11)
@@ -14,8 +15,9 @@
 // is 36 B per cell per half-step (read 3+3 fields, write 3).  Design rules applied:
 //   * one thread = 4 consecutive x-cells = one dwordx4 per field component; consecutive lanes
 //     read consecutive memory (rows are stored gap-free), so every wave access is 1 KiB coalesced;
-//   * operator coefficients are NOT streamed: one class byte per edge (3 B/cell) indexes a
-//     256-entry (vv, m) table staged in LDS, the mesh metric comes from 1-D tables in L1;
+//   * operator coefficients are NOT streamed: one class byte per CELL (1 B/cell; 3 B/cell when a
+//     scene has more than 256 distinct edge-class triples) indexes a (vv, m) table staged in LDS, the
+//     mesh metric comes from 1-D tables in L1;
 //   * blockIdx is remapped so that each XCD (own 4 MiB L2) sweeps one contiguous part of the slab,
 //     ordered strip-by-strip through z so the k+-1 and j+-1 neighbour rows are L2 hits;
 //   * CPML psi arrays exist only inside the layers; interior threads pay three compares.
@@ -33,8 +35,9 @@ __device__ __forceinline__ float4 sub4(const float4& a, const float4& b) {
 }
 
 // XCD-aware, strip-major block decode.  Returns false for threads beyond the strip.
-__device__ __forceinline__ bool decode(const DevParams& p, int k_begin, int nkr, int& k, int& j, int& i0) {
-  const unsigned nb = gridDim.x, b = blockIdx.x;
+__device__ __forceinline__ bool decode(const DevParams& p, int k_begin, int nkr, int extra, int& k, int& j, int& i0,
+                                       int& strip) {
+  const unsigned nb = gridDim.x - (unsigned)extra, b = blockIdx.x;
   const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
   const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
   const unsigned per_strip = (unsigned)nkr * (unsigned)p.nbs;
@@ -49,7 +52,34 @@ __device__ __forceinline__ bool decode(const DevParams& p, int k_begin, int nkr,
   const int jj = t / p.P4;
   j = (int)s * p.tys + jj;
   i0 = (t - jj * p.P4) * 4;
+  strip = (int)s;
   return true;
+}
+
+// value[step] = sum_e w[e]*field[e] for every probe of `kind` (one block, fixed reduction tree)
+__device__ __forceinline__ void probe_block(const DevParams& p, const int kind, const long long step, double* red) {
+  if (step < 0 || step >= p.max_steps) return;
+  for (int q = 0; q < p.nprobe; ++q) {
+    const DevProbe pr = p.probes[q];
+    if (pr.kind != kind) continue;
+    double s = 0.0;
+    for (int e = threadIdx.x; e < pr.n; e += FDTD_BLOCK) {
+      const float* F = (kind == FDTD_KIND_V ? p.V[pr.comp[e]] : p.I[pr.comp[e]]);
+      s = fma((double)pr.w[e], (double)F[pr.off[e]], s);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = FDTD_BLOCK / 2; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) pr.series[step] = red[0];
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void add_elem(float4& v, int e, float a) {
+  if (e == 0) v.x = v.x + a; else if (e == 1) v.y = v.y + a; else if (e == 2) v.z = v.z + a; else v.w = v.w + a;
 }
 
 __device__ __forceinline__ int pml_slot(const DevParams& p, int a, int q) {
@@ -103,15 +133,27 @@ __device__ __forceinline__ float4 upd4(const float4& ca, const float4& f, const 
 // ------------------------------------------------------------------------------------------------
 // K1: E half-step
 // ------------------------------------------------------------------------------------------------
-template <bool RAW, bool PML>
-__global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, const int k_begin, const int nkr) {
-  __shared__ float2 s_lut[256];
-  if (!RAW) {
+// COEF: 0 raw arrays, 1 class byte per edge, 2 one packed class byte per cell
+template <int COEF, bool PML, bool FUSE>
+__global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, const int k_begin, const int nkr,
+                                                         const long long step, const int extra) {
+  __shared__ float2 s_lut[COEF == 2 ? 768 : 256];
+  __shared__ double s_red[FUSE ? FDTD_BLOCK : 1];
+  if (FUSE && extra && blockIdx.x == gridDim.x - 1) {   // probe block: H-probes of the step just finished
+    probe_block(p, FDTD_KIND_I, step - 1, s_red);
+    return;
+  }
+  if (COEF == 1) {
     s_lut[threadIdx.x] = p.lut[threadIdx.x];
     __syncthreads();
+  } else if (COEF == 2) {
+    s_lut[threadIdx.x] = p.lut[threadIdx.x];
+    s_lut[threadIdx.x + 256] = p.lut[threadIdx.x + 256];
+    s_lut[threadIdx.x + 512] = p.lut[threadIdx.x + 512];
+    __syncthreads();
   }
-  int k, j, i0;
-  if (!decode(p, k_begin, nkr, k, j, i0)) return;
+  int k, j, i0, strip;
+  if (!decode(p, k_begin, nkr, extra, k, j, i0, strip)) return;
   const int off = k * p.plane + j * p.P + i0;
 
   const float4 ix = ld4(p.I[0] + off), iy = ld4(p.I[1] + off), iz = ld4(p.I[2] + off);
@@ -148,31 +190,60 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, cons
   }
 
   float4 ax, bx, ay, by, az, bz;
-  if (RAW) {
+  if (COEF == 0) {
     ax = ld4(p.vv + off); bx = ld4(p.vi + off);
     ay = ld4(p.vv + p.nloc + off); by = ld4(p.vi + p.nloc + off);
     az = ld4(p.vv + 2 * p.nloc + off); bz = ld4(p.vi + 2 * p.nloc + off);
   } else {
-    const uchar4 cx = *reinterpret_cast<const uchar4*>(p.ecls + off);
-    const uchar4 cy = *reinterpret_cast<const uchar4*>(p.ecls + p.nloc + off);
-    const uchar4 cz = *reinterpret_cast<const uchar4*>(p.ecls + 2 * p.nloc + off);
     const float4 ex0 = ld4(p.emet[0][0] + i0), ex1 = ld4(p.emet[1][0] + i0), ex2 = ld4(p.emet[2][0] + i0);
     const float m0 = p.emet[0][1][j] * p.emet[0][2][k];
     const float m1 = p.emet[1][1][j] * p.emet[1][2][k];
     const float m2 = p.emet[2][1][j] * p.emet[2][2][k];
-    float2 l0 = s_lut[cx.x], l1 = s_lut[cx.y], l2 = s_lut[cx.z], l3 = s_lut[cx.w];
-    ax = make_float4(l0.x, l1.x, l2.x, l3.x);
-    bx = make_float4(l0.y * (ex0.x * m0), l1.y * (ex0.y * m0), l2.y * (ex0.z * m0), l3.y * (ex0.w * m0));
-    l0 = s_lut[cy.x]; l1 = s_lut[cy.y]; l2 = s_lut[cy.z]; l3 = s_lut[cy.w];
-    ay = make_float4(l0.x, l1.x, l2.x, l3.x);
-    by = make_float4(l0.y * (ex1.x * m1), l1.y * (ex1.y * m1), l2.y * (ex1.z * m1), l3.y * (ex1.w * m1));
-    l0 = s_lut[cz.x]; l1 = s_lut[cz.y]; l2 = s_lut[cz.z]; l3 = s_lut[cz.w];
-    az = make_float4(l0.x, l1.x, l2.x, l3.x);
-    bz = make_float4(l0.y * (ex2.x * m2), l1.y * (ex2.y * m2), l2.y * (ex2.z * m2), l3.y * (ex2.w * m2));
+    float2 l0, l1, l2, l3;
+    if (COEF == 1) {
+      const uchar4 cx = *reinterpret_cast<const uchar4*>(p.ecls + off);
+      const uchar4 cy = *reinterpret_cast<const uchar4*>(p.ecls + p.nloc + off);
+      const uchar4 cz = *reinterpret_cast<const uchar4*>(p.ecls + 2 * p.nloc + off);
+      l0 = s_lut[cx.x]; l1 = s_lut[cx.y]; l2 = s_lut[cx.z]; l3 = s_lut[cx.w];
+      ax = make_float4(l0.x, l1.x, l2.x, l3.x);
+      bx = make_float4(l0.y * (ex0.x * m0), l1.y * (ex0.y * m0), l2.y * (ex0.z * m0), l3.y * (ex0.w * m0));
+      l0 = s_lut[cy.x]; l1 = s_lut[cy.y]; l2 = s_lut[cy.z]; l3 = s_lut[cy.w];
+      ay = make_float4(l0.x, l1.x, l2.x, l3.x);
+      by = make_float4(l0.y * (ex1.x * m1), l1.y * (ex1.y * m1), l2.y * (ex1.z * m1), l3.y * (ex1.w * m1));
+      l0 = s_lut[cz.x]; l1 = s_lut[cz.y]; l2 = s_lut[cz.z]; l3 = s_lut[cz.w];
+      az = make_float4(l0.x, l1.x, l2.x, l3.x);
+      bz = make_float4(l0.y * (ex2.x * m2), l1.y * (ex2.y * m2), l2.y * (ex2.z * m2), l3.y * (ex2.w * m2));
+    } else {
+      const uchar4 cc = *reinterpret_cast<const uchar4*>(p.ecls + off);
+      const int c0 = 3 * cc.x, c1 = 3 * cc.y, c2 = 3 * cc.z, c3 = 3 * cc.w;
+      l0 = s_lut[c0]; l1 = s_lut[c1]; l2 = s_lut[c2]; l3 = s_lut[c3];
+      ax = make_float4(l0.x, l1.x, l2.x, l3.x);
+      bx = make_float4(l0.y * (ex0.x * m0), l1.y * (ex0.y * m0), l2.y * (ex0.z * m0), l3.y * (ex0.w * m0));
+      l0 = s_lut[c0 + 1]; l1 = s_lut[c1 + 1]; l2 = s_lut[c2 + 1]; l3 = s_lut[c3 + 1];
+      ay = make_float4(l0.x, l1.x, l2.x, l3.x);
+      by = make_float4(l0.y * (ex1.x * m1), l1.y * (ex1.y * m1), l2.y * (ex1.z * m1), l3.y * (ex1.w * m1));
+      l0 = s_lut[c0 + 2]; l1 = s_lut[c1 + 2]; l2 = s_lut[c2 + 2]; l3 = s_lut[c3 + 2];
+      az = make_float4(l0.x, l1.x, l2.x, l3.x);
+      bz = make_float4(l0.y * (ex2.x * m2), l1.y * (ex2.y * m2), l2.y * (ex2.z * m2), l3.y * (ex2.w * m2));
+    }
   }
   vx = upd4(ax, vx, bx, dx1, dx2);
   vy = upd4(ay, vy, by, dy1, dy2);
   vz = upd4(az, vz, bz, dz1, dz2);
+  if (FUSE && p.nsrc > 0 && p.src_flag[k * p.nstrips + strip]) {
+    // soft voltage sources on edges of this strip-plane: V += amp * sig[step - delay]
+    for (int e = 0; e < p.nsrc; ++e) {
+      const unsigned rel = (unsigned)(p.src_off[e] - off);
+      if (rel < 4u) {
+        const long long t = step - p.src_delay[e];
+        if (t >= 0 && t < p.nsig) {
+          const float a = p.src_amp[e] * p.sig[t];
+          const int cmp = p.src_comp[e];
+          if (cmp == 0) add_elem(vx, (int)rel, a); else if (cmp == 1) add_elem(vy, (int)rel, a); else add_elem(vz, (int)rel, a);
+        }
+      }
+    }
+  }
   st4(p.V[0] + off, vx);
   st4(p.V[1] + off, vy);
   st4(p.V[2] + off, vz);
@@ -182,9 +253,15 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, cons
 // K2: H half-step
 // ------------------------------------------------------------------------------------------------
 template <bool RAW, bool PML>
-__global__ __launch_bounds__(FDTD_BLOCK) void k_update_H(const DevParams p, const int k_begin, const int nkr) {
-  int k, j, i0;
-  if (!decode(p, k_begin, nkr, k, j, i0)) return;
+__global__ __launch_bounds__(FDTD_BLOCK) void k_update_H(const DevParams p, const int k_begin, const int nkr,
+                                                         const long long step, const int extra) {
+  __shared__ double s_red[FDTD_BLOCK];
+  if (extra && blockIdx.x == gridDim.x - 1) {   // probe block: V-probes of this step (V is final, H not read)
+    probe_block(p, FDTD_KIND_V, step, s_red);
+    return;
+  }
+  int k, j, i0, strip;
+  if (!decode(p, k_begin, nkr, extra, k, j, i0, strip)) return;
   const int off = k * p.plane + j * p.P + i0;
 
   const float4 vx = ld4(p.V[0] + off), vy = ld4(p.V[1] + off), vz = ld4(p.V[2] + off);
@@ -288,45 +365,21 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_mur(const DevParams p, const Mur
 // ------------------------------------------------------------------------------------------------
 // K3: sources + probes (+ step++ after the H half-step).  Single block.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(FDTD_BLOCK) void k_post(const DevParams p, const int kind, const int nsrc,
-                                                     const int* __restrict__ src_off, const int8_t* __restrict__ src_comp,
-                                                     const float* __restrict__ src_amp, const int* __restrict__ src_delay,
-                                                     const float* __restrict__ sig, const int nsig, const int nprobe,
-                                                     const DevProbe* __restrict__ probes, long long* d_step,
-                                                     const int max_steps) {
+__global__ __launch_bounds__(FDTD_BLOCK) void k_post(const DevParams p, const int kind, const int sources,
+                                                     const long long step) {
   __shared__ double red[FDTD_BLOCK];
-  const long long step = *d_step;
-  if (kind == FDTD_KIND_V) {
-    for (int e = threadIdx.x; e < nsrc; e += FDTD_BLOCK) {
-      const long long t = step - src_delay[e];
-      if (t >= 0 && t < nsig) {
-        float* v = p.V[src_comp[e]] + src_off[e];
-        *v = *v + src_amp[e] * sig[t];
+  if (sources) {
+    for (int e = threadIdx.x; e < p.nsrc; e += FDTD_BLOCK) {
+      const long long t = step - p.src_delay[e];
+      if (t >= 0 && t < p.nsig) {
+        float* v = p.V[p.src_comp[e]] + p.src_off[e];
+        *v = *v + p.src_amp[e] * p.sig[t];
       }
     }
-    __syncthreads();  // single block: sources land before the probes read
     __threadfence_block();
+    __syncthreads();  // single block: sources land before the probes read
   }
-  if (step < max_steps) {
-    for (int q = 0; q < nprobe; ++q) {
-      const DevProbe pr = probes[q];
-      if (pr.kind != kind) continue;
-      double s = 0.0;
-      for (int e = threadIdx.x; e < pr.n; e += FDTD_BLOCK) {
-        const float* F = (kind == FDTD_KIND_V ? p.V[pr.comp[e]] : p.I[pr.comp[e]]);
-        s = fma((double)pr.w[e], (double)F[pr.off[e]], s);
-      }
-      red[threadIdx.x] = s;
-      __syncthreads();
-      for (int w = FDTD_BLOCK / 2; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-        __syncthreads();
-      }
-      if (threadIdx.x == 0) pr.series[step] = red[0];
-      __syncthreads();
-    }
-  }
-  if (kind == FDTD_KIND_I && threadIdx.x == 0) *d_step = step + 1;
+  probe_block(p, kind, step, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -334,8 +387,7 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_post(const DevParams p, const in
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(FDTD_BLOCK) void k_dft(const DevParams p, const int kind, const DevBox* __restrict__ boxes,
                                                     const int nfreq, const int every, const int nsamples,
-                                                    const double* __restrict__ tw, const long long* d_step) {
-  const long long step = *d_step;
+                                                    const double* __restrict__ tw, const long long step) {
   if (step % every != 0) return;
   const long long smp = step / every;
   if (smp >= nsamples) return;
@@ -402,29 +454,40 @@ void choose_tiling(fdtd_ctx* c) {
   c->p.nstrips = (ny + best - 1) / best;
 }
 
-void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, hipStream_t s) {
+template <int COEF, bool PML>
+static void launch_E2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long step, bool fused, int extra, hipStream_t s) {
+  if (fused) hipLaunchKernelGGL((k_update_E<COEF, PML, true>), grid, dim3(FDTD_BLOCK), 0, s, c->p, k_begin, nkr, step, extra);
+  else hipLaunchKernelGGL((k_update_E<COEF, PML, false>), grid, dim3(FDTD_BLOCK), 0, s, c->p, k_begin, nkr, step, 0);
+}
+
+void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool fused, bool probe_block, hipStream_t s) {
   const int nkr = k_end - k_begin;
   if (nkr <= 0) return;
-  const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs)), block(FDTD_BLOCK);
-  if (c->raw_op) {
-    if (c->have_cpml) hipLaunchKernelGGL((k_update_E<true, true>), grid, block, 0, s, c->p, k_begin, nkr);
-    else hipLaunchKernelGGL((k_update_E<true, false>), grid, block, 0, s, c->p, k_begin, nkr);
+  const int extra = (fused && probe_block) ? 1 : 0;
+  const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs + extra));
+  const int coef = c->raw_op ? 0 : (c->packed_op ? 2 : 1);
+  if (c->have_cpml) {
+    if (coef == 0) launch_E2<0, true>(c, grid, k_begin, nkr, step, fused, extra, s);
+    else if (coef == 1) launch_E2<1, true>(c, grid, k_begin, nkr, step, fused, extra, s);
+    else launch_E2<2, true>(c, grid, k_begin, nkr, step, fused, extra, s);
   } else {
-    if (c->have_cpml) hipLaunchKernelGGL((k_update_E<false, true>), grid, block, 0, s, c->p, k_begin, nkr);
-    else hipLaunchKernelGGL((k_update_E<false, false>), grid, block, 0, s, c->p, k_begin, nkr);
+    if (coef == 0) launch_E2<0, false>(c, grid, k_begin, nkr, step, fused, extra, s);
+    else if (coef == 1) launch_E2<1, false>(c, grid, k_begin, nkr, step, fused, extra, s);
+    else launch_E2<2, false>(c, grid, k_begin, nkr, step, fused, extra, s);
   }
 }
 
-void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, hipStream_t s) {
+void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s) {
   const int nkr = k_end - k_begin;
   if (nkr <= 0) return;
-  const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs)), block(FDTD_BLOCK);
+  const int extra = probe_block ? 1 : 0;
+  const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs + extra)), block(FDTD_BLOCK);
   if (c->raw_op) {
-    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<true, true>), grid, block, 0, s, c->p, k_begin, nkr);
-    else hipLaunchKernelGGL((k_update_H<true, false>), grid, block, 0, s, c->p, k_begin, nkr);
+    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<true, true>), grid, block, 0, s, c->p, k_begin, nkr, step, extra);
+    else hipLaunchKernelGGL((k_update_H<true, false>), grid, block, 0, s, c->p, k_begin, nkr, step, extra);
   } else {
-    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<false, true>), grid, block, 0, s, c->p, k_begin, nkr);
-    else hipLaunchKernelGGL((k_update_H<false, false>), grid, block, 0, s, c->p, k_begin, nkr);
+    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<false, true>), grid, block, 0, s, c->p, k_begin, nkr, step, extra);
+    else hipLaunchKernelGGL((k_update_H<false, false>), grid, block, 0, s, c->p, k_begin, nkr, step, extra);
   }
 }
 
@@ -455,16 +518,17 @@ void launch_mur(fdtd_ctx* c, int mode, hipStream_t s) {
   hipLaunchKernelGGL(k_mur, grid, block, 0, s, c->p, m, mode);
 }
 
-void launch_post(fdtd_ctx* c, int kind, hipStream_t s) {
-  if (c->nfreq && c->nbox && (c->step % c->every) == 0 && c->box_maxpts[kind] > 0) {
-    long pts = c->box_maxpts[kind];
-    unsigned gx = (unsigned)((pts + FDTD_BLOCK - 1) / FDTD_BLOCK);
-    if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_dft, dim3(gx, (unsigned)c->nbox), dim3(FDTD_BLOCK), 0, s, c->p, kind, c->d_box, c->nfreq,
-                       c->every, c->nsamples, kind == FDTD_KIND_V ? c->tw_v : c->tw_i, c->d_step);
-  }
-  hipLaunchKernelGGL(k_post, dim3(1), dim3(FDTD_BLOCK), 0, s, c->p, kind, c->nsrc, c->src_off, c->src_comp, c->src_amp,
-                     c->src_delay, c->sig, c->nsig, c->nprobe, c->d_probe, c->d_step, c->d.max_steps);
+void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s) {
+  if (!(c->nfreq && c->nbox && (step % c->every) == 0 && c->box_maxpts[kind] > 0)) return;
+  const long pts = c->box_maxpts[kind];
+  unsigned gx = (unsigned)((pts + FDTD_BLOCK - 1) / FDTD_BLOCK);
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(k_dft, dim3(gx, (unsigned)c->nbox), dim3(FDTD_BLOCK), 0, s, c->p, kind, c->d_box, c->nfreq,
+                     c->every, c->nsamples, kind == FDTD_KIND_V ? c->tw_v : c->tw_i, step);
+}
+
+void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_t s) {
+  hipLaunchKernelGGL(k_post, dim3(1), dim3(FDTD_BLOCK), 0, s, c->p, kind, sources ? 1 : 0, step);
 }
 
 void launch_energy(fdtd_ctx* c, hipStream_t s) {

@@ -35,6 +35,11 @@ from .nf2ff import calc_nf2ff, NF2FFResult
 
 _AX = {"x": 0, "y": 1, "z": 2, 0: 0, 1: 1, 2: 2}
 
+# Test hook: a library exporting the same C ABI that Run() uses instead of libfdtd_hip.so when the
+# front object was created without lib= (tests/ put the CPU oracle here to drive the reference's own
+# solver files through this module on a GPU-less host).  The product never sets it.
+_default_lib = None
+
 
 def _plain(v):
     if isinstance(v, np.ndarray):
@@ -341,7 +346,7 @@ class openEMS:
         self.calls_log.add("Run", verbose=verbose, cleanup=cleanup)
         if self._csx is None or self._f0 is None:
             raise RuntimeError("SetCSX and SetGaussExcite must be called before Run")
-        lib = self._lib or load_hip_library()
+        lib = self._lib or _default_lib or load_hip_library()
         grid, sc = self._build_scene()
         vox = voxelize(sc, grid)
         bc = BoundarySpec.parse(self._bc, self._cpml_cells)

@@ -27,6 +27,7 @@
 #include "../include/fdtd_hip.h"
 
 #include <math.h>
+#include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -87,6 +88,10 @@ static int fail(fdtd_ctx* c, int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+
+/* oracle-only helpers (not part of the product ABI): thread count for the cpu_baseline timing leg */
+void fdtd_oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int fdtd_oracle_get_threads(void) { return omp_get_max_threads(); }
 
 int fdtd_version(void) { return FDTD_ABI_VERSION; }
 int fdtd_device_count(void) { return 0; }

@@ -75,6 +75,23 @@ def test_port_probes_dft_energy(hip_lib, oracle_lib):
     assert abs(evh - evo) <= 1e-10 * evo and abs(eih - eio) <= 1e-10 * eio
 
 
+def test_chunked_runs_and_fused_probes(hip_lib, oracle_lib):
+    """fdtd_run in uneven chunks (probe flush at every call end, sources fused into update_E) must give
+    the same series as the oracle's plain loop."""
+    sh, so = patch_sim(48, 44, 32, nr_ts=700), patch_sim(48, 44, 32, nr_ts=700)
+    eh, eo = sh.build(hip_lib), so.build(oracle_lib)
+    for n in (1, 2, 97, 250, 349, 1):
+        eh.run(n)
+    eo.run(700)
+    assert eh.step == eo.step == 700
+    (uh, ih), (uo, io) = sh.port_series()[0], so.port_series()[0]
+    assert len(uh) == 700 and np.abs(uo).max() > 0 and np.abs(io).max() > 0
+    assert rel_l2(uh, uo) < 1e-12 and rel_l2(ih, io) < 1e-12
+    assert same_values(eh.fields(), eo.fields())
+    for a, b in zip(sh.nf2ff_boxes(), so.nf2ff_boxes()):
+        assert rel_l2(a, b) < 1e-12
+
+
 def test_farfield_matches_oracle(hip_lib, oracle_lib):
     capi = pkg("_capi")
     rng = np.random.default_rng(5)
