@@ -111,7 +111,7 @@ def main():
     ms_dom = max(ms_e, ms_h)
     achieved = algo_bytes / (ms_dom * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload, dom, world),
                 "kernel": dom, "ms_update_E": round(ms_e, 5), "ms_update_H": round(ms_h, 5),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "ms_per_timestep_profiled": round(prof.ms_total / prof.steps, 5),
@@ -145,6 +145,27 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(workload, kernel, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction) — profiles/<round>/
+    pmc_traffic_<workload>_*.json.  Counters cannot be collected from inside this process, so this is
+    null unless a committed measurement exists for this workload at N = 1."""
+    import glob
+    if world != 1:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{workload}_*.json")))
+    if not files:
+        return None
+    try:
+        data = json.load(open(files[-1]))["per_launch_traffic"]
+        for name, rec in data.items():
+            if kernel.replace("update_", "k_update_") in name:
+                return round(rec["total_bytes"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def usable_cores() -> int:
     """Host cores this process may really use: min(affinity mask, cgroup cpu.max quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -168,15 +189,18 @@ def cpu_baseline(capi, simm, w, vox, args):
     ora = capi.bind(ctypes.CDLL(so))
     ora.fdtd_oracle_set_threads(cores)
     cores = int(ora.fdtd_oracle_get_threads())
-    steps = args.cpu_steps or max(10, int(2.0e9 / w.grid.ncells))   # ~2e9 cell-steps: 10-30 s of CPU work
+    nr_cap = 20000
     sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=args.cpml_cells,
-                          nr_ts=steps + 16, nf2ff_freqs=[w.f0])
+                          nr_ts=nr_cap, nf2ff_freqs=[w.f0])
     e = sim.build(ora)
     rng = np.random.default_rng(0)
     for kind in (0, 1):        # non-zero start: avoids x86 denormal stalls of the all-zero initial state
         for c in range(3):
             e.set_field(kind, c, (1e-3 * rng.standard_normal(e.local_shape)).astype(np.float32))
-    e.run(4)
+    t0 = time.perf_counter()
+    e.run(8)                   # pilot: sizes the sample to ~12 s of CPU work
+    pilot = (time.perf_counter() - t0) / 8
+    steps = args.cpu_steps or int(min(nr_cap - 16, max(10, 12.0 / max(pilot, 1e-6))))
     t0 = time.perf_counter()
     e.run(steps)
     dt = time.perf_counter() - t0
