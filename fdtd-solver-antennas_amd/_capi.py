@@ -36,10 +36,10 @@ class FdtdDesc(C.Structure):
 class FdtdProfile(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_update_e", C.c_double), ("ms_update_h", C.c_double),
                 ("launches_e", C.c_int32), ("launches_h", C.c_int32),
-                ("steps", C.c_int32), ("reserved", C.c_int32)]
+                ("steps", C.c_int32), ("fused", C.c_int32)]
 
 
-FLAG_KERNEL_AUTO, FLAG_KERNEL_DIRECT, FLAG_KERNEL_LDS, FLAG_NO_GRAPH = 0, 1, 2, 0x10
+FLAG_KERNEL_AUTO, FLAG_KERNEL_DIRECT, FLAG_KERNEL_FUSED, FLAG_NO_GRAPH = 0, 1, 2, 0x10
 KIND_V, KIND_I = 0, 1
 PHASE_E, PHASE_H = 0, 1
 HALO_H_UP, HALO_E_DOWN = 0, 1

@@ -147,7 +147,8 @@ void fdtd_destroy(fdtd_ctx* c) {
   }
   for (int b = 0; b < c->nbox; ++b) hipFree(c->box[b].acc);
   hipFree(c->d_probe); hipFree(c->d_box); hipFree(c->tw_v); hipFree(c->tw_i);
-  hipFree(c->d_energy); hipFree(c->src_flag);
+  hipFree(c->d_energy); hipFree(c->src_flag); hipFree(c->src_flag2);
+  for (int n = 0; n < 6; ++n) { hipFree(c->fieldbase2[n]); hipFree(c->psi2[n]); }
   if (c->ev_E) hipEventDestroy(c->ev_E);
   if (c->ev_H) hipEventDestroy(c->ev_H);
   if (c->ev_haloE) hipEventDestroy(c->ev_haloE);
@@ -184,8 +185,9 @@ int fdtd_set_operator_classes(fdtd_ctx* c, const uint8_t* ecls, int ncls, const 
   const size_t n = 3 * c->nloc;
   for (size_t q = 0; q < (size_t)3 * nk * ny * nx; ++q)
     if (ecls[q] >= ncls) return fdtd_fail(c, FDTD_E_ARG, "class %d >= ncls %d", (int)ecls[q], ncls);
-  if (!c->ecls) HIPCK(c, hipMalloc(&c->ecls, n));
-  HIPCK(c, hipMemset(c->ecls, 0, n));
+  const size_t n_alloc = n + (size_t)c->plane + 64;   // slack: the fused kernel reads the class bytes of plane k+1
+  if (!c->ecls) HIPCK(c, hipMalloc(&c->ecls, n_alloc));
+  HIPCK(c, hipMemset(c->ecls, 0, n_alloc));
   // One byte per CELL when the scene has <= 256 distinct (cx, cy, cz) class triples (1 B instead of
   // 3 B per cell-step of coefficient traffic); otherwise one byte per edge.
   {
@@ -227,7 +229,9 @@ int fdtd_set_operator_classes(fdtd_ctx* c, const uint8_t* ecls, int ncls, const 
   }
   // metric tables: per (E|H, comp): x (padded to P, zeros), y, z — each segment 4-float aligned
   auto al4 = [](int v) { return (v + 3) / 4 * 4; };
-  const int seg = P + al4(ny) + al4(nk);
+  // +4 floats of zero slack per table: the fused kernel reads the entries of cell i0+4, row j+1, plane k+1
+  const int sx_ = P + 4, sy_ = al4(ny) + 4, sz_ = al4(nk) + 4;
+  const int seg = sx_ + sy_ + sz_;
   std::vector<float> host((size_t)6 * seg, 0.f);
   const int tl = nx + ny + nk;
   for (int eh = 0; eh < 2; ++eh)
@@ -235,16 +239,16 @@ int fdtd_set_operator_classes(fdtd_ctx* c, const uint8_t* ecls, int ncls, const 
       const float* src = (eh ? hmet : emet) + (size_t)comp * tl;
       float* dst = host.data() + (size_t)(eh * 3 + comp) * seg;
       memcpy(dst, src, nx * sizeof(float));
-      memcpy(dst + P, src + nx, ny * sizeof(float));
-      memcpy(dst + P + al4(ny), src + nx + ny, nk * sizeof(float));
+      memcpy(dst + sx_, src + nx, ny * sizeof(float));
+      memcpy(dst + sx_ + sy_, src + nx + ny, nk * sizeof(float));
     }
   if (!c->met) HIPCK(c, hipMalloc(&c->met, host.size() * sizeof(float)));
   HIPCK(c, hipMemcpy(c->met, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
   for (int comp = 0; comp < 3; ++comp) {
     const float* e = c->met + (size_t)comp * seg;
     const float* h = c->met + (size_t)(3 + comp) * seg;
-    c->p.emet[comp][0] = e; c->p.emet[comp][1] = e + P; c->p.emet[comp][2] = e + P + al4(ny);
-    c->p.hmet[comp][0] = h; c->p.hmet[comp][1] = h + P; c->p.hmet[comp][2] = h + P + al4(ny);
+    c->p.emet[comp][0] = e; c->p.emet[comp][1] = e + sx_; c->p.emet[comp][2] = e + sx_ + sy_;
+    c->p.hmet[comp][0] = h; c->p.hmet[comp][1] = h + sx_; c->p.hmet[comp][2] = h + sx_ + sy_;
   }
   c->p.ecls = c->ecls; c->p.lut = c->lut;
   c->have_op = true; c->raw_op = false;
@@ -273,7 +277,7 @@ int fdtd_set_cpml(fdtd_ctx* c, const int32_t* sx, const int32_t* sy, const int32
   // coefficient tables -> device, x tables padded to P (identity)
   const int nx = c->d.nx, ny = c->d.ny, nk = c->d.nk, P = c->P;
   auto al4 = [](int v) { return (v + 3) / 4 * 4; };
-  const int len[3] = {P, al4(ny), al4(nk)};
+  const int len[3] = {P + 4, al4(ny) + 4, al4(nk) + 4};
   const int nn[3] = {nx, ny, nk};
   size_t tot = 0;
   for (int a = 0; a < 3; ++a) tot += (size_t)6 * len[a];
@@ -304,13 +308,15 @@ int fdtd_set_cpml(fdtd_ctx* c, const int32_t* sx, const int32_t* sy, const int32
         const int a = (comp + 1 + w) % 3;
         float* ptr = nullptr;
         // allocate at least 16 B so interior kernels always hold a valid pointer
-        const size_t bytes = std::max<size_t>(psz[a] * sizeof(float), 16);
+        const size_t bytes = psz[a] * sizeof(float) + 64;   // slack for the fused kernel's o+4 reads
         HIPCK(c, hipMalloc(&ptr, bytes));
         HIPCK(c, hipMemset(ptr, 0, bytes));
         c->psi[(eh * 3 + comp) * 2 + w] = ptr;
         (eh ? c->p.psiH : c->p.psiE)[comp][w] = ptr;
       }
   c->have_cpml = (nsx + nsy + nsz) > 0;
+  c->psi_bytes[0] = psz[0] * sizeof(float) + 64; c->psi_bytes[1] = psz[1] * sizeof(float) + 64; c->psi_bytes[2] = psz[2] * sizeof(float) + 64;
+  c->fused_ready = false;
   return FDTD_OK;
 }
 
@@ -385,6 +391,7 @@ int fdtd_add_source(fdtd_ctx* c, int n, const int64_t* idx, const int8_t* comp, 
     }
     HIPCK(c, hipMemcpy(c->src_flag, flag.data(), flag.size(), hipMemcpyHostToDevice));
   }
+  c->fused_ready = false;
   c->p.nsrc = c->nsrc; c->p.src_off = c->src_off; c->p.src_comp = c->src_comp; c->p.src_amp = c->src_amp;
   c->p.src_delay = c->src_delay;
   return FDTD_OK;
@@ -533,6 +540,56 @@ static int exchange(fdtd_ctx* c, int which) {
   return FDTD_OK;
 }
 
+static bool fused_eligible(const fdtd_ctx* c) {
+  return c->d.world == 1 && !c->any_mur && c->have_op && !c->raw_op;
+}
+
+// Second buffer set for the one-pass kernel (fields + psi_E), dilated source flags.
+static int ensure_fused(fdtd_ctx* c) {
+  if (c->fused_ready) return FDTD_OK;
+  const size_t fbytes = (size_t)c->plane * (c->d.nk + 2) * sizeof(float);
+  for (int n = 0; n < 6; ++n) {
+    if (!c->fieldbase2[n]) {
+      HIPCK(c, hipMalloc(&c->fieldbase2[n], fbytes));
+      HIPCK(c, hipMemset(c->fieldbase2[n], 0, fbytes));
+    }
+  }
+  // which of the two allocations is "current" is tracked by p.V/p.I; the partner is the other one
+  for (int n = 0; n < 3; ++n) {
+    float* a = c->fieldbase[n] + c->plane; float* b = c->fieldbase2[n] + c->plane;
+    c->p.Vn[n] = (c->p.V[n] == a) ? b : a;
+    a = c->fieldbase[3 + n] + c->plane; b = c->fieldbase2[3 + n] + c->plane;
+    c->p.In[n] = (c->p.I[n] == a) ? b : a;
+  }
+  for (int comp = 0; comp < 3; ++comp)
+    for (int w = 0; w < 2; ++w) {
+      const int q = comp * 2 + w, ax = (comp + 1 + w) % 3;
+      hipFree(c->psi2[q]); c->psi2[q] = nullptr;
+      const size_t bytes = c->have_cpml ? c->psi_bytes[ax] : 64;
+      HIPCK(c, hipMalloc(&c->psi2[q], bytes));
+      HIPCK(c, hipMemset(c->psi2[q], 0, bytes));
+      c->p.psiEn[comp][w] = c->psi2[q];
+      if (!c->have_cpml) c->p.psiE[comp][w] = c->psi2[q];
+    }
+  {
+    const int ns = c->p.nstrips, tys = c->p.tys, nk = c->d.nk;
+    std::vector<uint8_t> flag((size_t)nk * ns, 0);
+    for (int off : c->h_src_off) {
+      const int k = off / c->plane, j = (off - k * c->plane) / c->P;
+      for (int kk = k - 1; kk <= k; ++kk)
+        for (int jj = j - 1; jj <= j; ++jj)
+          if (kk >= 0 && jj >= 0) flag[(size_t)kk * ns + jj / tys] = 1;
+    }
+    if (!c->src_flag2) HIPCK(c, hipMalloc(&c->src_flag2, flag.size()));
+    HIPCK(c, hipMemcpy(c->src_flag2, flag.data(), flag.size(), hipMemcpyHostToDevice));
+    c->p.src_flag2 = c->src_flag2;
+  }
+  c->fused_ready = true;
+  return FDTD_OK;
+}
+
+static int step_loop_fused(fdtd_ctx* c, int nsteps, struct ProfEvents* pe);
+
 struct ProfEvents {
   std::vector<hipEvent_t> e0, e1, h0, h1;
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -542,6 +599,12 @@ struct ProfEvents {
 // and the probes are sampled by one extra block of the main kernels (update_H(n): V-probes of step n;
 // update_E(n+1): I-probes of step n; the last step's I-probes are flushed at the end of the call).
 static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
+  const unsigned kmode = c->d.flags & FDTD_FLAG_KERNEL_MASK;
+  if (kmode == FDTD_FLAG_KERNEL_FUSED && !fused_eligible(c))
+    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "fused kernel needs a single slab, a class operator and no Mur faces");
+  // AUTO currently resolves to the two-pass kernels (faster on MI355X as measured, profiles/r01); the
+  // one-pass kernel is opt-in until its CPML path is restructured.
+  if (kmode == FDTD_FLAG_KERNEL_FUSED) return step_loop_fused(c, nsteps, pe);
   const int nk = c->d.nk;
   const bool multi = c->d.world > 1;
   if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_comm_init (RCCL) or drive fdtd_half_step + fdtd_halo_*");
@@ -591,6 +654,32 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   return FDTD_OK;
 }
 
+// One launch per step: new V, I (and psi_E) go to the partner buffers, then the roles swap.  The probe block
+// of launch n samples both probe kinds of step n-1; the last step is flushed by stand-alone launches.
+static int step_loop_fused(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
+  int r = ensure_fused(c);
+  if (r) return r;
+  hipStream_t s = c->stream;
+  for (int n = 0; n < nsteps; ++n) {
+    const long long step = c->step;
+    if (pe) HIPCK(c, hipEventRecord(pe->e0[n], s));
+    launch_step_fused(c, step, true, s);
+    if (pe) { HIPCK(c, hipEventRecord(pe->e1[n], s)); HIPCK(c, hipEventRecord(pe->h0[n], s)); HIPCK(c, hipEventRecord(pe->h1[n], s)); }
+    for (int q = 0; q < 3; ++q) { std::swap(c->p.V[q], c->p.Vn[q]); std::swap(c->p.I[q], c->p.In[q]); }
+    for (int comp = 0; comp < 3; ++comp)
+      for (int w = 0; w < 2; ++w) std::swap(c->p.psiE[comp][w], c->p.psiEn[comp][w]);
+    launch_dft(c, FDTD_KIND_V, step, s);
+    launch_dft(c, FDTD_KIND_I, step, s);
+    c->step++;
+  }
+  if (nsteps > 0) {
+    launch_post(c, FDTD_KIND_V, c->step - 1, false, s);
+    launch_post(c, FDTD_KIND_I, c->step - 1, false, s);
+  }
+  HIPCK(c, hipGetLastError());
+  return FDTD_OK;
+}
+
 int fdtd_run(fdtd_ctx* c, int nsteps) {
   int r = check_ready(c);
   if (r) return r;
@@ -628,6 +717,7 @@ int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
       hipEventElapsedTime(&ms, pe.h0[n], pe.h1[n]); sh += ms;
     }
     out->ms_update_e = se / nsteps; out->ms_update_h = sh / nsteps;
+    out->fused = ((c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_FUSED) ? 1 : 0;
     out->launches_e = out->launches_h = nsteps;
   }
   for (auto* v : {&pe.e0, &pe.e1, &pe.h0, &pe.h1}) for (auto e : *v) hipEventDestroy(e);

@@ -20,8 +20,10 @@ struct DevParams {
   int nx, ny, nk, P, P4;
   int plane;  // ny * P (floats)
   int nloc;   // nk * plane
-  float* V[3];
+  float* V[3];               // current fields (local plane 0; ghost planes at -plane and +nk*plane)
   float* I[3];
+  float* Vn[3];              // fused one-pass kernel: next-step buffers (ping-pong), else null
+  float* In[3];
   // operator: raw arrays [3][nk*plane] or class bytes + LUT + 1-D metric tables
   const float* vv; const float* vi; const float* ii; const float* iv;
   const uint8_t* ecls;       // class mode: [3][nloc] one byte per edge; packed mode: [nloc] one byte per cell
@@ -34,6 +36,8 @@ struct DevParams {
   const float* cp[3][2][3];  // [axis][E-loc/H-loc][b, c, 1/kappa]
   float* psiE[3][2];
   float* psiH[3][2];
+  float* psiEn[3][2];        // fused kernel: next-step psi_E (ping-pong); psi_H is updated in place
+  const uint8_t* src_flag2;  // fused kernel: strip-plane flag dilated by one row / one plane
   // launch tiling: a block = 256 threads = 1024 consecutive x-cells of one strip of `tys` rows in one plane
   int tys, nbs, nstrips;
   // fused soft sources (update_E) and probes (extra block of update_E / update_H)
@@ -54,6 +58,11 @@ struct fdtd_ctx {
   int P = 0, plane = 0;
   size_t nloc = 0;               // nk*plane
   float* fieldbase[6] = {};      // allocations incl. ghosts
+  float* fieldbase2[6] = {};     // ping-pong partner (fused kernel), allocated on first fused run
+  float* psi2[6] = {};           // ping-pong partner of the six psi_E arrays
+  uint8_t* src_flag2 = nullptr;
+  bool fused_ready = false;
+  size_t psi_bytes[3] = {64, 64, 64};
   float *vv = nullptr, *vi = nullptr, *ii = nullptr, *iv = nullptr;
   uint8_t* ecls = nullptr;
   float2* lut = nullptr;
@@ -105,5 +114,7 @@ void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool p
 void launch_mur(fdtd_ctx* c, int mode, hipStream_t s);
 void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_t s);   // stand-alone sources + probes
 void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);
+// fused.hip: one launch = E half-step + H half-step of all owned planes, current -> next buffers
+void launch_step_fused(fdtd_ctx* c, long long step, bool probe_block, hipStream_t s);
 void launch_energy(fdtd_ctx* c, hipStream_t s);
 void choose_tiling(fdtd_ctx* c);

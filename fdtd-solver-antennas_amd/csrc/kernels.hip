@@ -24,111 +24,9 @@
 //
 // Float32 operation order is pinned with explicit fmaf (compiled with -ffp-contract=off) and is
 // identical to oracle/fdtd_oracle.c, so results are compared bit for bit.
-#include "fdtd_ctx.h"
+#include "kernel_common.hpp"
 
 namespace {
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ float4 sub4(const float4& a, const float4& b) {
-  return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-}
-
-// XCD-aware, strip-major block decode.  Returns false for threads beyond the strip.
-__device__ __forceinline__ bool decode(const DevParams& p, int k_begin, int nkr, int extra, int& k, int& j, int& i0,
-                                       int& strip) {
-  const unsigned nb = gridDim.x - (unsigned)extra, b = blockIdx.x;
-  const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
-  const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-  const unsigned per_strip = (unsigned)nkr * (unsigned)p.nbs;
-  const unsigned s = v / per_strip;
-  const unsigned rem = v - s * per_strip;
-  const unsigned kk = rem / (unsigned)p.nbs;
-  const unsigned pb = rem - kk * (unsigned)p.nbs;
-  k = k_begin + (int)kk;
-  const int t = (int)pb * FDTD_BLOCK + (int)threadIdx.x;
-  const int rows = min(p.tys, p.ny - (int)s * p.tys);
-  if (t >= rows * p.P4) return false;
-  const int jj = t / p.P4;
-  j = (int)s * p.tys + jj;
-  i0 = (t - jj * p.P4) * 4;
-  strip = (int)s;
-  return true;
-}
-
-// value[step] = sum_e w[e]*field[e] for every probe of `kind` (one block, fixed reduction tree)
-__device__ __forceinline__ void probe_block(const DevParams& p, const int kind, const long long step, double* red) {
-  if (step < 0 || step >= p.max_steps) return;
-  for (int q = 0; q < p.nprobe; ++q) {
-    const DevProbe pr = p.probes[q];
-    if (pr.kind != kind) continue;
-    double s = 0.0;
-    for (int e = threadIdx.x; e < pr.n; e += FDTD_BLOCK) {
-      const float* F = (kind == FDTD_KIND_V ? p.V[pr.comp[e]] : p.I[pr.comp[e]]);
-      s = fma((double)pr.w[e], (double)F[pr.off[e]], s);
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = FDTD_BLOCK / 2; w > 0; w >>= 1) {
-      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) pr.series[step] = red[0];
-    __syncthreads();
-  }
-}
-
-__device__ __forceinline__ void add_elem(float4& v, int e, float a) {
-  if (e == 0) v.x = v.x + a; else if (e == 1) v.y = v.y + a; else if (e == 2) v.z = v.z + a; else v.w = v.w + a;
-}
-
-__device__ __forceinline__ int pml_slot(const DevParams& p, int a, int q) {
-  return q < p.pml_lo[a] ? q : (q >= p.pml_hi[a] ? q - p.pml_hi[a] + p.pml_hi_slot[a] : -1);
-}
-
-// psi <- b*psi + c*d ; d <- d/kappa + psi   for the four cells of a thread (row-uniform coefficients)
-__device__ __forceinline__ void cpml_row4(float4& d, float* psi, float b, float c, float ik) {
-  float4 ps = ld4(psi);
-  ps.x = __builtin_fmaf(b, ps.x, c * d.x);
-  ps.y = __builtin_fmaf(b, ps.y, c * d.y);
-  ps.z = __builtin_fmaf(b, ps.z, c * d.z);
-  ps.w = __builtin_fmaf(b, ps.w, c * d.w);
-  st4(psi, ps);
-  d.x = __builtin_fmaf(ik, d.x, ps.x);
-  d.y = __builtin_fmaf(ik, d.y, ps.y);
-  d.z = __builtin_fmaf(ik, d.z, ps.z);
-  d.w = __builtin_fmaf(ik, d.w, ps.w);
-}
-
-// x-directed layers: per-cell coefficients, psi stored [k][j][nslot_x]
-__device__ __forceinline__ void cpml_x4(const DevParams& p, int eh, int i0, int rowslot, float4& da, float* psia,
-                                        float4& db, float* psib) {
-  float a[4] = {da.x, da.y, da.z, da.w};
-  float bb[4] = {db.x, db.y, db.z, db.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int i = i0 + e;
-    const int sx = pml_slot(p, 0, i);
-    if (sx >= 0 && i < p.nx) {
-      const float b = p.cp[0][eh][0][i], c = p.cp[0][eh][1][i], ik = p.cp[0][eh][2][i];
-      const int o = rowslot + sx;
-      float ps = __builtin_fmaf(b, psia[o], c * a[e]);
-      psia[o] = ps;
-      a[e] = __builtin_fmaf(ik, a[e], ps);
-      ps = __builtin_fmaf(b, psib[o], c * bb[e]);
-      psib[o] = ps;
-      bb[e] = __builtin_fmaf(ik, bb[e], ps);
-    }
-  }
-  da = make_float4(a[0], a[1], a[2], a[3]);
-  db = make_float4(bb[0], bb[1], bb[2], bb[3]);
-}
-
-__device__ __forceinline__ float4 upd4(const float4& ca, const float4& f, const float4& cb, const float4& d1,
-                                       const float4& d2) {
-  return make_float4(__builtin_fmaf(ca.x, f.x, cb.x * (d1.x - d2.x)), __builtin_fmaf(ca.y, f.y, cb.y * (d1.y - d2.y)),
-                     __builtin_fmaf(ca.z, f.z, cb.z * (d1.z - d2.z)), __builtin_fmaf(ca.w, f.w, cb.w * (d1.w - d2.w)));
-}
 
 // ------------------------------------------------------------------------------------------------
 // K1: E half-step

@@ -68,9 +68,9 @@ enum { FDTD_HALO_H_UP = 0, FDTD_HALO_E_DOWN = 1 };   /* Ix,Iy top plane -> rank+
 
 /* Kernel selection (fdtd_desc.flags) — all variants compute bit-identical results. */
 enum {
-  FDTD_FLAG_KERNEL_AUTO   = 0,
-  FDTD_FLAG_KERNEL_DIRECT = 1,   /* one thread = 4 x-cells, neighbours through L1/L2 */
-  FDTD_FLAG_KERNEL_LDS    = 2,   /* LDS-tiled, z-marching */
+  FDTD_FLAG_KERNEL_AUTO   = 0,   /* the faster variant for the scene (currently the two-pass kernels) */
+  FDTD_FLAG_KERNEL_DIRECT = 1,   /* two-pass leapfrog: one E launch + one H launch per step */
+  FDTD_FLAG_KERNEL_FUSED  = 2,   /* one-pass leapfrog (E+H in one launch, ping-pong buffers); error if not eligible */
   FDTD_FLAG_KERNEL_MASK   = 0xF,
   FDTD_FLAG_NO_GRAPH      = 0x10 /* do not capture the step loop into a hipGraph */
 };
@@ -94,7 +94,7 @@ typedef struct fdtd_profile {
   int32_t launches_e;     /* launches averaged */
   int32_t launches_h;
   int32_t steps;
-  int32_t reserved;
+  int32_t fused;          /* 1: one fused launch per step (ms_update_e = that launch, ms_update_h = 0) */
 } fdtd_profile;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
