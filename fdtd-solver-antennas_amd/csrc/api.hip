@@ -273,6 +273,15 @@ int fdtd_set_cpml(fdtd_ctx* c, const int32_t* sx, const int32_t* sy, const int32
     const int used = lo + (n - hi);
     if (used != ns[a]) return fdtd_fail(c, FDTD_E_ARG, "cpml axis %d: %d slots declared, %d used", a, ns[a], used);
     c->p.pml_lo[a] = lo; c->p.pml_hi[a] = hi < n ? hi : (1 << 30); c->p.pml_hi_slot[a] = lo; c->p.nslot[a] = ns[a];
+    if (a == 0) {
+      // internal x layout: both ranges start on a 4-cell boundary, so a thread's four cells are one aligned
+      // float4 of psi (cells drawn in that are outside the real layer carry identity coefficients)
+      const int lo4 = (lo + 3) / 4 * 4;
+      int ahi = hi < n ? hi / 4 * 4 : (1 << 30);
+      if (ahi < lo4) ahi = lo4;
+      c->p.pml_lo[0] = lo4; c->p.pml_hi[0] = ahi; c->p.pml_hi_slot[0] = lo4;
+      c->p.nslot[0] = lo4 + (hi < n ? c->P - ahi : 0);
+    }
   }
   // coefficient tables -> device, x tables padded to P (identity)
   const int nx = c->d.nx, ny = c->d.ny, nk = c->d.nk, P = c->P;
@@ -300,7 +309,7 @@ int fdtd_set_cpml(fdtd_ctx* c, const int32_t* sx, const int32_t* sy, const int32
     for (int eh = 0; eh < 2; ++eh)
       for (int w = 0; w < 3; ++w) c->p.cp[a][eh][w] = c->cpcoef + tab_off[a][eh][w];
   // psi: axis x -> [nk][ny][nsx]; y -> [nk][nsy][P]; z -> [nsz][ny][P]
-  const size_t psz[3] = {(size_t)nk * ny * nsx, (size_t)nk * nsy * P, (size_t)nsz * ny * P};
+  const size_t psz[3] = {(size_t)nk * ny * c->p.nslot[0], (size_t)nk * nsy * P, (size_t)nsz * ny * P};
   for (int n = 0; n < 12; ++n) { hipFree(c->psi[n]); c->psi[n] = nullptr; }
   for (int eh = 0; eh < 2; ++eh)
     for (int comp = 0; comp < 3; ++comp)
@@ -572,7 +581,8 @@ static int ensure_fused(fdtd_ctx* c) {
       if (!c->have_cpml) c->p.psiE[comp][w] = c->psi2[q];
     }
   {
-    const int ns = c->p.nstrips, tys = c->p.tys, nk = c->d.nk;
+    choose_tiling_fused(c);
+    const int ns = c->p.nstrips2, tys = c->p.tys2, nk = c->d.nk;
     std::vector<uint8_t> flag((size_t)nk * ns, 0);
     for (int off : c->h_src_off) {
       const int k = off / c->plane, j = (off - k * c->plane) / c->P;
@@ -580,7 +590,8 @@ static int ensure_fused(fdtd_ctx* c) {
         for (int jj = j - 1; jj <= j; ++jj)
           if (kk >= 0 && jj >= 0) flag[(size_t)kk * ns + jj / tys] = 1;
     }
-    if (!c->src_flag2) HIPCK(c, hipMalloc(&c->src_flag2, flag.size()));
+    hipFree(c->src_flag2); c->src_flag2 = nullptr;
+    HIPCK(c, hipMalloc(&c->src_flag2, flag.size()));
     HIPCK(c, hipMemcpy(c->src_flag2, flag.data(), flag.size(), hipMemcpyHostToDevice));
     c->p.src_flag2 = c->src_flag2;
   }

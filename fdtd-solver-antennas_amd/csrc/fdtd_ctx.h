@@ -40,6 +40,7 @@ struct DevParams {
   const uint8_t* src_flag2;  // fused kernel: strip-plane flag dilated by one row / one plane
   // launch tiling: a block = 256 threads = 1024 consecutive x-cells of one strip of `tys` rows in one plane
   int tys, nbs, nstrips;
+  int tys2, nbs2, nstrips2;  // tiling of the fused kernel (blocks of 4 x 63 owner groups)
   // fused soft sources (update_E) and probes (extra block of update_E / update_H)
   const uint8_t* src_flag;   // [nk][nstrips]: strip-plane contains a source edge
   int nsrc; const int* src_off; const int8_t* src_comp; const float* src_amp; const int* src_delay;
@@ -116,5 +117,6 @@ void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_
 void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);
 // fused.hip: one launch = E half-step + H half-step of all owned planes, current -> next buffers
 void launch_step_fused(fdtd_ctx* c, long long step, bool probe_block, hipStream_t s);
+void choose_tiling_fused(fdtd_ctx* c);
 void launch_energy(fdtd_ctx* c, hipStream_t s);
 void choose_tiling(fdtd_ctx* c);
