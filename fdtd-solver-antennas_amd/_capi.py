@@ -90,7 +90,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 
 def hip_library_path(lib_dir: Optional[str] = None) -> str:
-    return os.path.join(lib_dir or os.path.join(_HERE, "csrc"), HIP_LIB_NAME)
+    """<lib_dir>/libfdtd_hip.so; default: $FDTD_HIP_LIB_DIR, else the in-tree build under csrc/."""
+    return os.path.join(lib_dir or os.environ.get("FDTD_HIP_LIB_DIR") or os.path.join(_HERE, "csrc"), HIP_LIB_NAME)
 
 
 _hip_lib = None

@@ -114,6 +114,8 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
     p.I[n] = c->fieldbase[3 + n] + plane;
   }
   for (int a = 0; a < 3; ++a) { p.pml_lo[a] = 0; p.pml_hi[a] = 1 << 30; p.pml_hi_slot[a] = 0; p.nslot[a] = 0; }
+  // six field arrays + class bytes vs the 256 MiB Infinity Cache
+  p.nt = ((size_t)c->nloc * (6 * sizeof(float) + 1) > (size_t)200 << 20) ? 1 : 0;
   choose_tiling(c);
   {
     const size_t nflag = (size_t)d->nk * p.nstrips;

@@ -40,7 +40,8 @@ struct DevParams {
   const uint8_t* src_flag2;  // fused kernel: strip-plane flag dilated by one row / one plane
   // launch tiling: a block = 256 threads = 1024 consecutive x-cells of one strip of `tys` rows in one plane
   int tys, nbs, nstrips;
-  int tys2, nbs2, nstrips2;  // tiling of the fused kernel (blocks of 4 x 63 owner groups)
+  int tys2, nbs2, nstrips2;
+  int nt;                    // 1: non-temporal stores for the field outputs (working set beyond the Infinity Cache)  // tiling of the fused kernel (blocks of 4 x 63 owner groups)
   // fused soft sources (update_E) and probes (extra block of update_E / update_H)
   const uint8_t* src_flag;   // [nk][nstrips]: strip-plane contains a source edge
   int nsrc; const int* src_off; const int8_t* src_comp; const float* src_amp; const int* src_delay;

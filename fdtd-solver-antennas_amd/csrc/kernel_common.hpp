@@ -6,6 +6,17 @@ namespace {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+// streamed outputs: non-temporal once the working set exceeds the 256 MiB Infinity Cache (measured on
+// MI355X: +3-4 % at 400x400x80, -15 % at 300x300x60 where the fields live in the cache)
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4s(const int nt, float* p, const float4& v) {
+  if (nt) {
+    v4f_nt t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f_nt*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
+  }
+}
 __device__ __forceinline__ float4 sub4(const float4& a, const float4& b) {
   return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
 }

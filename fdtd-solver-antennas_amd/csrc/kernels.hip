@@ -142,9 +142,9 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, cons
       }
     }
   }
-  st4(p.V[0] + off, vx);
-  st4(p.V[1] + off, vy);
-  st4(p.V[2] + off, vz);
+  st4s(p.nt, p.V[0] + off, vx);
+  st4s(p.nt, p.V[1] + off, vy);
+  st4s(p.nt, p.V[2] + off, vz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -213,9 +213,9 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_H(const DevParams p, cons
     iz = make_float4(iz.x + (hx2.x * m2) * (dz1.x - dz2.x), iz.y + (hx2.y * m2) * (dz1.y - dz2.y),
                      iz.z + (hx2.z * m2) * (dz1.z - dz2.z), iz.w + (hx2.w * m2) * (dz1.w - dz2.w));
   }
-  st4(p.I[0] + off, ix);
-  st4(p.I[1] + off, iy);
-  st4(p.I[2] + off, iz);
+  st4s(p.nt, p.I[0] + off, ix);
+  st4s(p.nt, p.I[1] + off, iy);
+  st4s(p.nt, p.I[2] + off, iz);
 }
 
 // ------------------------------------------------------------------------------------------------
