@@ -186,3 +186,53 @@ def test_full_size_properties(hip_lib):
     assert np.isfinite(res[1][0]).all() and np.abs(res[1][0]).max() > 0
     assert rel_l2(res[2][0], 2.0 * res[1][0]) < 1e-6
     assert rel_l2(res[2][1], 2.0 * res[1][1]) < 1e-6
+
+
+def test_plugin_path_s11_and_patterns_gpu_vs_oracle(hip_lib, oracle_lib, tmp_path):
+    """North-star parity statement, end to end through the plugin surface: the same PatchAntennaParams
+    go through prepare_hip_microstrip_patch_3d / run_prepared_hip once on the GPU library and once on the
+    CPU oracle; S11(f) and the E/H-plane patterns must agree to 1e-3 relative L2 (they agree to ~1e-9:
+    the time stepping is bit-identical, only fp64 reductions differ)."""
+    s = pkg("solver_fdtd_hip")
+    sink = pkg("result_sink")
+    P = pkg("params").PatchAntennaParams
+    p = P.from_user_units(frequency_ghz=5.8, er=4.3, h_mm=1.6, loss_tangent=0.02)
+    res = []
+    for lib, tag in ((hip_lib, "gpu"), (oracle_lib, "cpu")):
+        prep = s.prepare_hip_microstrip_patch_3d(p, feed_direction=s.FeedDirection.NEG_X, boundary="PML_8", theta_step_deg=4.0,
+                                                 phi_step_deg=15.0, mesh_quality=1, work_dir=str(tmp_path / tag), _engine_lib=lib)
+        assert prep.ok, prep.message
+        prep.FDTD.NrTS = 2500
+        r = s.run_prepared_hip(prep, frequency_hz=5.8e9, verbose=0)
+        assert r.ok, r.message
+        res.append(r)
+    g, c = res
+    assert g.intensity.shape == c.intensity.shape == (46, 25)
+    assert rel_l2(g.s11, c.s11) < 1e-3 and rel_l2(g.port_u, c.port_u) < 1e-4 and rel_l2(g.port_i, c.port_i) < 1e-4
+    _, ge, gh = sink.principal_cuts(g.theta, g.phi, g.intensity)
+    _, ce, ch = sink.principal_cuts(c.theta, c.phi, c.intensity)
+    lin = lambda d: 10.0 ** (np.asarray(d) / 20.0)
+    assert rel_l2(lin(ge), lin(ce)) < 1e-3 and rel_l2(lin(gh), lin(ch)) < 1e-3
+    assert abs(g.Dmax - c.Dmax) < 1e-6 * c.Dmax
+    assert g.stats["steps"] == c.stats["steps"] and g.stats["grid"] == c.stats["grid"]
+    data = sink.write_result(g, str(tmp_path / "result.json"))
+    assert data["ok"] and len(data["e_plane_dBi"]) == 46
+
+
+def test_multi_patch_rotated_runs_on_gpu(hip_lib, tmp_path):
+    """Two elements, one rotated 90 deg about z and lifted, finite-thickness copper, volumetric lumped ports
+    (multi_3d variant): runs on the GPU, both ports deliver series, pattern is finite."""
+    s = pkg("solver_fdtd_hip")
+    P = pkg("params").PatchAntennaParams
+    p = P.from_user_units(frequency_ghz=5.8, er=4.3, h_mm=1.6, loss_tangent=0.02, metal_thickness_um=200.0)
+    arr = [s.PatchInstance("A", p, -0.02, 0.0, 0.0, s.FeedDirection.NEG_X),
+           s.PatchInstance("B", p, 0.02, 0.0, 0.002, s.FeedDirection.NEG_Y, rot_z_deg=90.0)]
+    prep = s.prepare_hip_microstrip_multi_3d(arr, boundary="PML_8", theta_step_deg=6.0, phi_step_deg=30.0, mesh_quality=1,
+                                             auto_margin_mm=(25.0, 25.0, 30.0), work_dir=str(tmp_path / "m"))
+    assert prep.ok, prep.message
+    prep.FDTD.NrTS = 1500
+    r = s.run_prepared_hip(prep, frequency_hz=5.8e9, verbose=0)
+    assert r.ok, r.message
+    assert np.isfinite(r.intensity).all() and r.intensity.shape == (31, 13)
+    series = prep.FDTD.sim.port_series()
+    assert len(series) == 2 and all(np.abs(u).max() > 0 and np.abs(i).max() > 0 for u, i in series)
