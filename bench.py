@@ -26,6 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "fdtd-solver-antennas_amd"
 
+SCENES = {"C2": "2.45 GHz patch on FR-4 (fixed scene)", "NS": "2.45 GHz patch on FR-4 (fixed scene)",
+          "C3": "2.45 GHz patch on FR-4 (fixed scene)", "C4": "5.8 GHz microstrip-fed patch (microstrip_3d geometry)",
+          "C5": "2x2 patch array, 61.2 mm pitch (multi_3d geometry)"}
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md: 8 TB/s; 6.29 TB/s measured copy ceiling)
 ALGO_BYTES_PER_CELL_HALFSTEP = 36.0   # read 3 + 3 field components, write 3 (fp32)
 
@@ -65,7 +68,7 @@ def main():
     simm = importlib.import_module(PKG + ".simulation")
     hip = capi.load_hip_library()           # raises if the HIP library is missing: no fallback
 
-    w = wl.patch_workload(args.workload)
+    w = wl.baseline_workload(args.workload)
     vox = sc.voxelize(w.scene, w.grid)
     nts_total = (args.steps + args.warmup) * args.ts_per_step * 2 + 8
     sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=args.cpml_cells,
@@ -133,8 +136,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w.grid.shape[0]}x{w.grid.shape[1]}x{w.grid.shape[2]} "
-                                   f"2.45 GHz patch on FR-4 (fixed scene), CPML-{args.cpml_cells}, lumped port, "
-                                   f"NF2FF DFT surfaces",
+                                   f"{SCENES.get(args.workload, 'patch')}, CPML-{args.cpml_cells}, "
+                                   f"{len(vox.ports)} lumped port(s), NF2FF DFT surfaces",
                        "cells": ncells, "timesteps_per_step": tps, "operator": sim.operator_form,
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
                        "fields_finite": finite},
