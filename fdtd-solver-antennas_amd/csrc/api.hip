@@ -44,6 +44,42 @@ static hipError_t to_device(T** dst, const std::vector<T>& v) {
   return hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
 }
 
+// Per strip-plane source lists (CSR) for a tiling of `tys` rows per strip: a source at (k, j) is listed in every
+// strip-plane (s, kk) with kk in [k - dk, k] and rows [s*tys - dj .. ) covering j, i.e. dj = dk = 0 for the
+// two-pass kernels and 1 for the fused kernel, whose threads also compute row j+1 and plane k+1.
+static hipError_t build_source_lists(const fdtd_ctx* c, int tys, int nstrips, int dil, int2** d_rng, int** d_ids,
+                                     int* max_len = nullptr) {
+  const int nk = c->d.nk;
+  std::vector<std::vector<int>> lists((size_t)nk * nstrips);
+  for (size_t e = 0; e < c->h_src_off.size(); ++e) {
+    const int off = c->h_src_off[e];
+    const int k = off / c->plane, j = (off - k * c->plane) / c->P;
+    for (int kk = k - dil; kk <= k; ++kk)
+      for (int jj = j - dil; jj <= j; ++jj) {
+        if (kk < 0 || jj < 0) continue;
+        auto& l = lists[(size_t)kk * nstrips + jj / tys];
+        if (l.empty() || l.back() != (int)e) l.push_back((int)e);
+      }
+  }
+  std::vector<int2> rng(lists.size());
+  std::vector<int> ids;
+  for (size_t q = 0; q < lists.size(); ++q) {
+    rng[q].x = (int)ids.size();
+    ids.insert(ids.end(), lists[q].begin(), lists[q].end());
+    rng[q].y = (int)ids.size();
+    if (max_len && (int)lists[q].size() > *max_len) *max_len = (int)lists[q].size();
+  }
+  hipFree(*d_rng); hipFree(*d_ids); *d_rng = nullptr; *d_ids = nullptr;
+  hipError_t err = hipMalloc(d_rng, rng.size() * sizeof(int2));
+  if (err != hipSuccess) return err;
+  err = hipMemcpy(*d_rng, rng.data(), rng.size() * sizeof(int2), hipMemcpyHostToDevice);
+  if (err != hipSuccess) return err;
+  err = hipMalloc(d_ids, std::max<size_t>(ids.size(), 1) * sizeof(int));
+  if (err != hipSuccess) return err;
+  if (!ids.empty()) err = hipMemcpy(*d_ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice);
+  return err;
+}
+
 extern "C" {
 
 int fdtd_version(void) { return FDTD_ABI_VERSION; }
@@ -117,15 +153,7 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   // six field arrays + class bytes vs the 256 MiB Infinity Cache
   p.nt = ((size_t)c->nloc * (6 * sizeof(float) + 1) > (size_t)200 << 20) ? 1 : 0;
   choose_tiling(c);
-  {
-    const size_t nflag = (size_t)d->nk * p.nstrips;
-    if (hipMalloc(&c->src_flag, nflag) != hipSuccess || hipMemset(c->src_flag, 0, nflag) != hipSuccess) {
-      fdtd_fail(nullptr, FDTD_E_NOMEM, "source flags");
-      fdtd_destroy(c);
-      return FDTD_E_NOMEM;
-    }
-  }
-  p.src_flag = c->src_flag; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
+  p.src_rng = nullptr; p.src_ids = nullptr; p.src_rng2 = nullptr; p.src_ids2 = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
   p.sig = c->sig; p.nsig = 0;
   p.probes = c->d_probe; p.nprobe = 0; p.max_steps = d->max_steps;
   *out = c;
@@ -149,7 +177,7 @@ void fdtd_destroy(fdtd_ctx* c) {
   }
   for (int b = 0; b < c->nbox; ++b) hipFree(c->box[b].acc);
   hipFree(c->d_probe); hipFree(c->d_box); hipFree(c->tw_v); hipFree(c->tw_i);
-  hipFree(c->d_energy); hipFree(c->src_flag); hipFree(c->src_flag2);
+  hipFree(c->d_energy); hipFree(c->src_rng); hipFree(c->src_ids); hipFree(c->src_rng2); hipFree(c->src_ids2);
   for (int n = 0; n < 6; ++n) { hipFree(c->fieldbase2[n]); hipFree(c->psi2[n]); }
   if (c->ev_E) hipEventDestroy(c->ev_E);
   if (c->ev_H) hipEventDestroy(c->ev_H);
@@ -394,14 +422,8 @@ int fdtd_add_source(fdtd_ctx* c, int n, const int64_t* idx, const int8_t* comp, 
   HIPCK(c, to_device(&c->src_comp, c->h_src_comp));
   HIPCK(c, to_device(&c->src_amp, c->h_src_amp));
   HIPCK(c, to_device(&c->src_delay, c->h_src_delay));
-  {
-    std::vector<uint8_t> flag((size_t)c->d.nk * c->p.nstrips, 0);
-    for (int off : c->h_src_off) {
-      const int k = off / c->plane, j = (off - k * c->plane) / c->P;
-      flag[(size_t)k * c->p.nstrips + j / c->p.tys] = 1;
-    }
-    HIPCK(c, hipMemcpy(c->src_flag, flag.data(), flag.size(), hipMemcpyHostToDevice));
-  }
+  HIPCK(c, build_source_lists(c, c->p.tys, c->p.nstrips, 0, &c->src_rng, &c->src_ids));
+  c->p.src_rng = c->src_rng; c->p.src_ids = c->src_ids;
   c->fused_ready = false;
   c->p.nsrc = c->nsrc; c->p.src_off = c->src_off; c->p.src_comp = c->src_comp; c->p.src_amp = c->src_amp;
   c->p.src_delay = c->src_delay;
@@ -582,21 +604,12 @@ static int ensure_fused(fdtd_ctx* c) {
       c->p.psiEn[comp][w] = c->psi2[q];
       if (!c->have_cpml) c->p.psiE[comp][w] = c->psi2[q];
     }
-  {
-    choose_tiling_fused(c);
-    const int ns = c->p.nstrips2, tys = c->p.tys2, nk = c->d.nk;
-    std::vector<uint8_t> flag((size_t)nk * ns, 0);
-    for (int off : c->h_src_off) {
-      const int k = off / c->plane, j = (off - k * c->plane) / c->P;
-      for (int kk = k - 1; kk <= k; ++kk)
-        for (int jj = j - 1; jj <= j; ++jj)
-          if (kk >= 0 && jj >= 0) flag[(size_t)kk * ns + jj / tys] = 1;
-    }
-    hipFree(c->src_flag2); c->src_flag2 = nullptr;
-    HIPCK(c, hipMalloc(&c->src_flag2, flag.size()));
-    HIPCK(c, hipMemcpy(c->src_flag2, flag.data(), flag.size(), hipMemcpyHostToDevice));
-    c->p.src_flag2 = c->src_flag2;
-  }
+  choose_tiling_fused(c);
+  int max_len = 0;
+  HIPCK(c, build_source_lists(c, c->p.tys2, c->p.nstrips2, 1, &c->src_rng2, &c->src_ids2, &max_len));
+  if (max_len > FDTD_BLOCK)
+    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "fused kernel: %d source edges in one strip-plane (limit %d)", max_len, FDTD_BLOCK);
+  c->p.src_rng2 = c->src_rng2; c->p.src_ids2 = c->src_ids2;
   c->fused_ready = true;
   return FDTD_OK;
 }

@@ -37,13 +37,15 @@ struct DevParams {
   float* psiE[3][2];
   float* psiH[3][2];
   float* psiEn[3][2];        // fused kernel: next-step psi_E (ping-pong); psi_H is updated in place
-  const uint8_t* src_flag2;  // fused kernel: strip-plane flag dilated by one row / one plane
+  const int2* src_rng2;      // fused kernel tiling: sources in rows [j0, j0+rows] x planes [k, k+1] of a strip-plane
+  const int* src_ids2;
   // launch tiling: a block = 256 threads = 1024 consecutive x-cells of one strip of `tys` rows in one plane
   int tys, nbs, nstrips;
   int tys2, nbs2, nstrips2;
   int nt;                    // 1: non-temporal stores for the field outputs (working set beyond the Infinity Cache)  // tiling of the fused kernel (blocks of 4 x 63 owner groups)
   // fused soft sources (update_E) and probes (extra block of update_E / update_H)
-  const uint8_t* src_flag;   // [nk][nstrips]: strip-plane contains a source edge
+  const int2* src_rng;       // [nk][nstrips]: range into src_ids of the sources inside that strip-plane
+  const int* src_ids;
   int nsrc; const int* src_off; const int8_t* src_comp; const float* src_amp; const int* src_delay;
   const float* sig; int nsig;
   const struct DevProbe* probes; int nprobe; int max_steps;
@@ -62,7 +64,7 @@ struct fdtd_ctx {
   float* fieldbase[6] = {};      // allocations incl. ghosts
   float* fieldbase2[6] = {};     // ping-pong partner (fused kernel), allocated on first fused run
   float* psi2[6] = {};           // ping-pong partner of the six psi_E arrays
-  uint8_t* src_flag2 = nullptr;
+  int2* src_rng2 = nullptr; int* src_ids2 = nullptr;
   bool fused_ready = false;
   size_t psi_bytes[3] = {64, 64, 64};
   float *vv = nullptr, *vi = nullptr, *ii = nullptr, *iv = nullptr;
@@ -70,7 +72,7 @@ struct fdtd_ctx {
   float2* lut = nullptr;
   float* met = nullptr;          // packed metric tables
   bool have_op = false, raw_op = false, packed_op = false;
-  uint8_t* src_flag = nullptr;
+  int2* src_rng = nullptr; int* src_ids = nullptr;
   // cpml
   bool have_cpml = false;
   float* cpcoef = nullptr;

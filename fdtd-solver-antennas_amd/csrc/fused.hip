@@ -68,42 +68,30 @@ __device__ __forceinline__ float4 shift_hi(const float4 a, const float next) {  
   return make_float4(a.x - a.y, a.y - a.z, a.z - a.w, a.w - next);
 }
 
-// soft sources that land in [o, o+3] for component comp: V += amp*sig[step-delay]
-__device__ __forceinline__ void add_sources(const DevParams& p, const long long step, const int comp, const int o, float4& v) {
-  for (int e = 0; e < p.nsrc; ++e) {
-    const unsigned rel = (unsigned)(p.src_off[e] - o);
-    if (rel < 4u && p.src_comp[e] == comp) {
-      const long long t = step - p.src_delay[e];
-      if (t >= 0 && t < p.nsig) add_elem(v, (int)rel, p.src_amp[e] * p.sig[t]);
-    }
-  }
-}
-
 template <int COEF, bool PML>
 __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_step_fused(const DevParams p, const long long step, const int extra) {
   __shared__ float2 s_lut[COEF == 2 ? 768 : 256];
   __shared__ double s_red[FDTD_BLOCK];
+  __shared__ SrcStage s_src;
   if (extra && blockIdx.x == gridDim.x - 1) {   // probe block: both probe kinds of the step just finished
     probe_block(p, FDTD_KIND_V, step - 1, s_red);
     probe_block(p, FDTD_KIND_I, step - 1, s_red);
     return;
   }
+  // ---- XCD-aware strip-major decode; 63 owner groups + 1 helper per wave ----
+  int strip, k, pb;
+  decode_block(p.nbs2, p.nk, extra, strip, k, pb);
   s_lut[threadIdx.x] = p.lut[threadIdx.x];
   if (COEF == 2) {
     s_lut[threadIdx.x + 256] = p.lut[threadIdx.x + 256];
     s_lut[threadIdx.x + 512] = p.lut[threadIdx.x + 512];
   }
+  int2 srng = make_int2(0, 0);
+  if (p.nsrc > 0) {   // sources touching this strip-plane's rows [j0, j0+rows] x planes [k, k+1]
+    srng = p.src_rng2[k * p.nstrips2 + strip];
+    stage_sources(p, p.src_ids2, srng.x, min(srng.y - srng.x, FDTD_BLOCK), step, s_src);
+  }
   __syncthreads();
-
-  // ---- XCD-aware strip-major decode; 63 owner groups + 1 helper per wave ----
-  const unsigned nb = gridDim.x - (unsigned)extra, b = blockIdx.x;
-  const unsigned q8 = nb >> 3, r8 = nb & 7u, xcd = b & 7u;
-  const unsigned v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-  const unsigned per_strip = (unsigned)p.nk * (unsigned)p.nbs2;
-  const int strip = (int)(v / per_strip);
-  const unsigned rem = v - (unsigned)strip * per_strip;
-  const int k = (int)(rem / (unsigned)p.nbs2);
-  const int pb = (int)(rem - (unsigned)k * (unsigned)p.nbs2);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j0 = strip * p.tys2;
   const int rows = min(p.tys2, p.ny - j0);
@@ -225,10 +213,11 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_step_fused(const DevParams p,
   vz_jp = vnew4(s_lut, cls4<COEF>(c_jp[2], 2), ex2, y2p * z2, vz_jp, bz1, bz2);
   vx_kp = vnew4(s_lut, cls4<COEF>(c_kp[0], 0), ex0, y0 * z0p, vx_kp, cx1, cx2);
   vy_kp = vnew4(s_lut, cls4<COEF>(c_kp[1], 1), ex1, y1 * z1p, vy_kp, cy1, cy2);
-  if (p.nsrc > 0 && p.src_flag2[k * p.nstrips2 + strip]) {
-    add_sources(p, step, 0, off, vx); add_sources(p, step, 1, off, vy); add_sources(p, step, 2, off, vz);
-    add_sources(p, step, 0, oj, vx_jp); add_sources(p, step, 2, oj, vz_jp);
-    add_sources(p, step, 0, ok, vx_kp); add_sources(p, step, 1, ok, vy_kp);
+  if (srng.y > srng.x) {
+    const int n = min(srng.y - srng.x, FDTD_BLOCK);   // (more than FDTD_BLOCK sources per strip-plane: see ensure_fused)
+    apply_staged(s_src, n, 0, off, vx); apply_staged(s_src, n, 1, off, vy); apply_staged(s_src, n, 2, off, vz);
+    apply_staged(s_src, n, 0, oj, vx_jp); apply_staged(s_src, n, 2, oj, vz_jp);
+    apply_staged(s_src, n, 0, ok, vx_kp); apply_staged(s_src, n, 1, ok, vy_kp);
   }
   // new voltages of cell i0+4 = first cell of the next lane's group (lane 63 of every wave is that helper)
   const float vy_ip = __shfl_down(vy.x, 1), vz_ip = __shfl_down(vz.x, 1);

@@ -21,26 +21,50 @@ __device__ __forceinline__ float4 sub4(const float4& a, const float4& b) {
   return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
 }
 
-// XCD-aware, strip-major block decode.  Returns false for threads beyond the strip.
-__device__ __forceinline__ bool decode(const DevParams& p, int k_begin, int nkr, int extra, int& k, int& j, int& i0,
-                                       int& strip) {
+// XCD-aware, strip-major block decode: block-uniform part (strip, plane, block within the strip-plane) ...
+__device__ __forceinline__ void decode_block(int nbs, int nkr, int extra, int& strip, int& kk, int& pb) {
   const unsigned nb = gridDim.x - (unsigned)extra, b = blockIdx.x;
   const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
   const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-  const unsigned per_strip = (unsigned)nkr * (unsigned)p.nbs;
+  const unsigned per_strip = (unsigned)nkr * (unsigned)nbs;
   const unsigned s = v / per_strip;
   const unsigned rem = v - s * per_strip;
-  const unsigned kk = rem / (unsigned)p.nbs;
-  const unsigned pb = rem - kk * (unsigned)p.nbs;
-  k = k_begin + (int)kk;
-  const int t = (int)pb * FDTD_BLOCK + (int)threadIdx.x;
-  const int rows = min(p.tys, p.ny - (int)s * p.tys);
+  const unsigned k = rem / (unsigned)nbs;
+  strip = (int)s; kk = (int)k; pb = (int)(rem - k * (unsigned)nbs);
+}
+// ... and the per-thread part.  Returns false for threads beyond the strip.
+__device__ __forceinline__ bool decode_thread(const DevParams& p, int strip, int pb, int& j, int& i0) {
+  const int t = pb * FDTD_BLOCK + (int)threadIdx.x;
+  const int rows = min(p.tys, p.ny - strip * p.tys);
   if (t >= rows * p.P4) return false;
   const int jj = t / p.P4;
-  j = (int)s * p.tys + jj;
+  j = strip * p.tys + jj;
   i0 = (t - jj * p.P4) * 4;
-  strip = (int)s;
   return true;
+}
+
+// Soft sources of one strip-plane, staged once per block: (flat offset | comp << 29 is avoided: two arrays)
+struct SrcStage { int off[FDTD_BLOCK]; float val[FDTD_BLOCK]; signed char comp[FDTD_BLOCK]; };
+// Fill the stage with sources [begin, begin+n) of the id list (n <= FDTD_BLOCK); value = amp*sig[step-delay] or 0.
+__device__ __forceinline__ void stage_sources(const DevParams& p, const int* ids, int begin, int n, long long step, SrcStage& st) {
+  const int q = threadIdx.x;
+  if (q < n) {
+    const int e = ids[begin + q];
+    const long long t = step - p.src_delay[e];
+    st.off[q] = p.src_off[e];
+    st.comp[q] = p.src_comp[e];
+    st.val[q] = (t >= 0 && t < p.nsig) ? p.src_amp[e] * p.sig[t] : 0.f;
+  }
+}
+// V += amp*sig for staged sources that fall on component `comp` of the four cells at flat offset o
+__device__ __forceinline__ void apply_staged(const SrcStage& st, int n, int comp, int o, float4& v) {
+  for (int q = 0; q < n; ++q) {
+    const unsigned rel = (unsigned)(st.off[q] - o);
+    if (rel < 4u && st.comp[q] == comp && st.val[q] != 0.f) {
+      const float a = st.val[q];
+      if (rel == 0) v.x = v.x + a; else if (rel == 1) v.y = v.y + a; else if (rel == 2) v.z = v.z + a; else v.w = v.w + a;
+    }
+  }
 }
 
 // value[step] = sum_e w[e]*field[e] for every probe of `kind` (one block, fixed reduction tree)

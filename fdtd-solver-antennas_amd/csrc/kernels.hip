@@ -35,23 +35,32 @@ namespace {
 template <int COEF, bool PML, bool FUSE>
 __global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, const int k_begin, const int nkr,
                                                          const long long step, const int extra) {
-  __shared__ float2 s_lut[COEF == 2 ? 768 : 256];
+  __shared__ float2 s_lut[COEF == 2 ? 768 : (COEF == 1 ? 256 : 1)];
   __shared__ double s_red[FUSE ? FDTD_BLOCK : 1];
+  __shared__ SrcStage s_src;
   if (FUSE && extra && blockIdx.x == gridDim.x - 1) {   // probe block: H-probes of the step just finished
     probe_block(p, FDTD_KIND_I, step - 1, s_red);
     return;
   }
+  int strip, kk, pb;
+  decode_block(p.nbs, nkr, extra, strip, kk, pb);
+  const int k = k_begin + kk;
   if (COEF == 1) {
     s_lut[threadIdx.x] = p.lut[threadIdx.x];
-    __syncthreads();
   } else if (COEF == 2) {
     s_lut[threadIdx.x] = p.lut[threadIdx.x];
     s_lut[threadIdx.x + 256] = p.lut[threadIdx.x + 256];
     s_lut[threadIdx.x + 512] = p.lut[threadIdx.x + 512];
-    __syncthreads();
   }
-  int k, j, i0, strip;
-  if (!decode(p, k_begin, nkr, extra, k, j, i0, strip)) return;
+  // soft sources inside this strip-plane (block-uniform range; almost always empty)
+  int2 srng = make_int2(0, 0);
+  if (FUSE && p.nsrc > 0) {
+    srng = p.src_rng[k * p.nstrips + strip];
+    stage_sources(p, p.src_ids, srng.x, min(srng.y - srng.x, FDTD_BLOCK), step, s_src);
+  }
+  if (COEF != 0 || (FUSE && p.nsrc > 0)) __syncthreads();
+  int j, i0;
+  if (!decode_thread(p, strip, pb, j, i0)) return;
   const int off = k * p.plane + j * p.P + i0;
 
   const float4 ix = ld4(p.I[0] + off), iy = ld4(p.I[1] + off), iz = ld4(p.I[2] + off);
@@ -128,9 +137,15 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, cons
   vx = upd4(ax, vx, bx, dx1, dx2);
   vy = upd4(ay, vy, by, dy1, dy2);
   vz = upd4(az, vz, bz, dz1, dz2);
-  if (FUSE && p.nsrc > 0 && p.src_flag[k * p.nstrips + strip]) {
-    // soft voltage sources on edges of this strip-plane: V += amp * sig[step - delay]
-    for (int e = 0; e < p.nsrc; ++e) {
+  if (FUSE && srng.y > srng.x) {
+    // V += amp * sig[step - delay] on the edges of this strip-plane: the first FDTD_BLOCK from the LDS stage,
+    // any overflow (never seen in the reference's scenes) straight from global memory
+    const int n = min(srng.y - srng.x, FDTD_BLOCK);
+    apply_staged(s_src, n, 0, off, vx);
+    apply_staged(s_src, n, 1, off, vy);
+    apply_staged(s_src, n, 2, off, vz);
+    for (int q = srng.x + FDTD_BLOCK; q < srng.y; ++q) {
+      const int e = p.src_ids[q];
       const unsigned rel = (unsigned)(p.src_off[e] - off);
       if (rel < 4u) {
         const long long t = step - p.src_delay[e];
@@ -158,8 +173,10 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_H(const DevParams p, cons
     probe_block(p, FDTD_KIND_V, step, s_red);
     return;
   }
-  int k, j, i0, strip;
-  if (!decode(p, k_begin, nkr, extra, k, j, i0, strip)) return;
+  int strip, kk, pb, j, i0;
+  decode_block(p.nbs, nkr, extra, strip, kk, pb);
+  const int k = k_begin + kk;
+  if (!decode_thread(p, strip, pb, j, i0)) return;
   const int off = k * p.plane + j * p.P + i0;
 
   const float4 vx = ld4(p.V[0] + off), vy = ld4(p.V[1] + off), vz = ld4(p.V[2] + off);
