@@ -248,6 +248,7 @@ int fdtd_set_operator_classes(fdtd_ctx* c, const uint8_t* ecls, int ncls, const 
       hipFree(c->lut); c->lut = nullptr;
       HIPCK(c, hipMalloc(&c->lut, 768 * sizeof(float2)));
       HIPCK(c, hipMemcpy(c->lut, lut3.data(), 768 * sizeof(float2), hipMemcpyHostToDevice));
+      c->p.lut_n = (int)(3 * triples.size());
     } else {
       HIPCK(c, upload_rows(c->ecls, P, ecls, nx, (size_t)3 * nk * ny));
       std::vector<float2> lut(256, make_float2(0.f, 0.f));
@@ -255,6 +256,7 @@ int fdtd_set_operator_classes(fdtd_ctx* c, const uint8_t* ecls, int ncls, const 
       hipFree(c->lut); c->lut = nullptr;
       HIPCK(c, hipMalloc(&c->lut, 256 * sizeof(float2)));
       HIPCK(c, hipMemcpy(c->lut, lut.data(), 256 * sizeof(float2), hipMemcpyHostToDevice));
+      c->p.lut_n = ncls;
     }
   }
   // metric tables: per (E|H, comp): x (padded to P, zeros), y, z — each segment 4-float aligned

@@ -28,6 +28,7 @@ struct DevParams {
   const float* vv; const float* vi; const float* ii; const float* iv;
   const uint8_t* ecls;       // class mode: [3][nloc] one byte per edge; packed mode: [nloc] one byte per cell
   const float2* lut;         // class mode: [256] (vv, m); packed mode: [256][3] (vv, m) per component
+  int lut_n;                 // entries actually used (only these are staged in LDS)
   const float* emet[3][3];   // [comp][axis], x tables padded to P with zeros
   const float* hmet[3][3];
   // CPML: index q along axis a is in a layer iff q < pml_lo[a] (slot q) or q >= pml_hi[a]

@@ -81,11 +81,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_step_fused(const DevParams p,
   // ---- XCD-aware strip-major decode; 63 owner groups + 1 helper per wave ----
   int strip, k, pb;
   decode_block(p.nbs2, p.nk, extra, strip, k, pb);
-  s_lut[threadIdx.x] = p.lut[threadIdx.x];
-  if (COEF == 2) {
-    s_lut[threadIdx.x + 256] = p.lut[threadIdx.x + 256];
-    s_lut[threadIdx.x + 512] = p.lut[threadIdx.x + 512];
-  }
+  for (int q = threadIdx.x; q < p.lut_n; q += FDTD_BLOCK) s_lut[q] = p.lut[q];
   int2 srng = make_int2(0, 0);
   if (p.nsrc > 0) {   // sources touching this strip-plane's rows [j0, j0+rows] x planes [k, k+1]
     srng = p.src_rng2[k * p.nstrips2 + strip];

@@ -45,13 +45,8 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, cons
   int strip, kk, pb;
   decode_block(p.nbs, nkr, extra, strip, kk, pb);
   const int k = k_begin + kk;
-  if (COEF == 1) {
-    s_lut[threadIdx.x] = p.lut[threadIdx.x];
-  } else if (COEF == 2) {
-    s_lut[threadIdx.x] = p.lut[threadIdx.x];
-    s_lut[threadIdx.x + 256] = p.lut[threadIdx.x + 256];
-    s_lut[threadIdx.x + 512] = p.lut[threadIdx.x + 512];
-  }
+  if (COEF != 0)
+    for (int q = threadIdx.x; q < p.lut_n; q += FDTD_BLOCK) s_lut[q] = p.lut[q];
   // soft sources inside this strip-plane (block-uniform range; almost always empty)
   int2 srng = make_int2(0, 0);
   if (FUSE && p.nsrc > 0) {
