@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "fdtd_last_error", "fdtd_set_operator_raw", "fdtd_set_operator_classes", "fdtd_set_cpml",
     "fdtd_set_mur", "fdtd_set_signal", "fdtd_add_source", "fdtd_add_probe", "fdtd_get_probe",
     "fdtd_set_dft", "fdtd_add_dft_box", "fdtd_get_dft_box", "fdtd_run", "fdtd_run_profiled",
-    "fdtd_get_step", "fdtd_energy", "fdtd_comm_unique_id", "fdtd_comm_init", "fdtd_half_step",
+    "fdtd_get_step", "fdtd_energy", "fdtd_comm_unique_id", "fdtd_comm_init", "fdtd_link", "fdtd_run_linked", "fdtd_half_step",
     "fdtd_halo_get", "fdtd_halo_put", "fdtd_get_field", "fdtd_set_field", "fdtd_farfield",
 ]
 
@@ -74,6 +74,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
         "fdtd_energy": (C.c_int, [p, p]),
         "fdtd_comm_unique_id": (C.c_int, [p]),
         "fdtd_comm_init": (C.c_int, [p, p]),
+        "fdtd_link": (C.c_int, [p, p]),
+        "fdtd_run_linked": (C.c_int, [C.POINTER(p), C.c_int, C.c_int]),
         "fdtd_half_step": (C.c_int, [p, C.c_int]),
         "fdtd_halo_get": (C.c_int, [p, C.c_int, p]),
         "fdtd_halo_put": (C.c_int, [p, C.c_int, p]),
@@ -318,6 +320,15 @@ class Engine:
     def fields(self):
         """All six components as [2][3][nk][ny][nx]."""
         return np.stack([np.stack([self.get_field(kind, c) for c in range(3)]) for kind in (KIND_V, KIND_I)])
+
+
+def run_linked(engines, nsteps: int):
+    """Step adjacent slabs that live in this process together (fdtd_link + fdtd_run_linked)."""
+    lib = engines[0].lib
+    for lo, hi in zip(engines[:-1], engines[1:]):
+        lo._ck(lib.fdtd_link(lo._ctx, hi._ctx), "link")
+    arr = (C.c_void_p * len(engines))(*[e._ctx for e in engines])
+    engines[0]._ck(lib.fdtd_run_linked(arr, len(engines), int(nsteps)), "run_linked")
 
 
 def comm_unique_id(lib: C.CDLL) -> bytes:

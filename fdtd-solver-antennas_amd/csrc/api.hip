@@ -541,14 +541,12 @@ static int check_ready(fdtd_ctx* c) {
 
 // Halo exchange on the communication stream.  which = FDTD_HALO_E_DOWN: Vx,Vy plane 0 -> rank-1, ghost
 // plane nk <- rank+1.  FDTD_HALO_H_UP: Ix,Iy plane nk-1 -> rank+1, ghost plane -1 <- rank-1.
-static int exchange(fdtd_ctx* c, int which) {
+// (a) RCCL: one grouped ncclSend/ncclRecv per exchange, xGMI peer-to-peer.
+static int exchange_rccl(fdtd_ctx* c, int which) {
   ncclComm_t comm = (ncclComm_t)c->comm;
   const int r = c->d.rank, w = c->d.world;
   const size_t cnt = (size_t)c->plane;
   const long top = (long)(c->d.nk - 1) * c->plane;
-  hipEvent_t after = which == FDTD_HALO_E_DOWN ? c->ev_E : c->ev_H;
-  HIPCK(c, hipEventRecord(after, c->stream));
-  HIPCK(c, hipStreamWaitEvent(c->comm_stream, after, 0));
   NCCLCK(c, ncclGroupStart());
   if (which == FDTD_HALO_E_DOWN) {
     if (r > 0) {
@@ -570,6 +568,39 @@ static int exchange(fdtd_ctx* c, int which) {
     }
   }
   NCCLCK(c, ncclGroupEnd());
+  return FDTD_OK;
+}
+
+// (b) contexts linked inside one process (fdtd_link): every context PULLS its ghost plane from the
+// neighbour with a peer copy on its own communication stream, after the neighbour's phase event.
+static int exchange_linked(fdtd_ctx* c, int which) {
+  const size_t bytes = (size_t)c->plane * sizeof(float);
+  if (which == FDTD_HALO_E_DOWN) {
+    fdtd_ctx* up = c->link_hi;
+    if (up) {
+      HIPCK(c, hipStreamWaitEvent(c->comm_stream, up->ev_E, 0));
+      for (int q = 0; q < 2; ++q)
+        HIPCK(c, hipMemcpyPeerAsync(c->p.V[q] + c->nloc, c->d.device, up->p.V[q], up->d.device, bytes, c->comm_stream));
+    }
+  } else {
+    fdtd_ctx* lo = c->link_lo;
+    if (lo) {
+      const long top = (long)(lo->d.nk - 1) * lo->plane;
+      HIPCK(c, hipStreamWaitEvent(c->comm_stream, lo->ev_H, 0));
+      for (int q = 0; q < 2; ++q)
+        HIPCK(c, hipMemcpyPeerAsync(c->p.I[q] - c->plane, c->d.device, lo->p.I[q] + top, lo->d.device, bytes, c->comm_stream));
+    }
+  }
+  return FDTD_OK;
+}
+
+static int exchange(fdtd_ctx* c, int which) {
+  HIPCK(c, hipSetDevice(c->d.device));
+  // nothing of this exchange may start before this slab's own half-step is complete (it both produces the
+  // plane that leaves and is the last reader of the ghost plane that is about to be overwritten)
+  HIPCK(c, hipStreamWaitEvent(c->comm_stream, which == FDTD_HALO_E_DOWN ? c->ev_E : c->ev_H, 0));
+  int r = c->comm ? exchange_rccl(c, which) : exchange_linked(c, which);
+  if (r) return r;
   if (which == FDTD_HALO_E_DOWN) { HIPCK(c, hipEventRecord(c->ev_haloE, c->comm_stream)); c->haloE_pending = true; }
   else { HIPCK(c, hipEventRecord(c->ev_haloH, c->comm_stream)); c->haloH_pending = true; }
   return FDTD_OK;
@@ -616,8 +647,6 @@ static int ensure_fused(fdtd_ctx* c) {
   return FDTD_OK;
 }
 
-static int step_loop_fused(fdtd_ctx* c, int nsteps, struct ProfEvents* pe);
-
 struct ProfEvents {
   std::vector<hipEvent_t> e0, e1, h0, h1;
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -626,58 +655,74 @@ struct ProfEvents {
 // One leapfrog step = two main launches.  Without Mur faces the soft sources are injected inside update_E
 // and the probes are sampled by one extra block of the main kernels (update_H(n): V-probes of step n;
 // update_E(n+1): I-probes of step n; the last step's I-probes are flushed at the end of the call).
+//
+// Multi-slab schedule (RCCL ranks or linked contexts): the E halo is only needed by the TOP plane of the H
+// sweep and the H halo only by the BOTTOM plane of the next E sweep, so every sweep launches all other planes
+// first (overlapping the exchange in flight on the communication stream), then waits for the halo event and
+// launches the one dependent plane.
+static int phase_E(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
+  HIPCK(c, hipSetDevice(c->d.device));
+  const int nk = c->d.nk;
+  const long long step = c->step;
+  hipStream_t s = c->stream;
+  launch_mur(c, 0, s);
+  if (pe) HIPCK(c, hipEventRecord(pe->e0[n], s));
+  const bool split = multi && c->d.rank > 0;
+  launch_update_E(c, split ? 1 : 0, nk, step, fused, true, s);
+  if (pe) HIPCK(c, hipEventRecord(pe->e1[n], s));
+  if (c->haloH_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloH, 0)); c->haloH_pending = false; }
+  // linked transport: the lower neighbour pulls my plane 0 itself; do not overwrite it before that copy ran
+  if (split && !c->comm && c->link_lo && c->link_lo->haloE_issued) HIPCK(c, hipStreamWaitEvent(s, c->link_lo->ev_haloE, 0));
+  if (split) launch_update_E(c, 0, 1, step, fused, false, s);
+  if (!fused) {
+    launch_mur(c, 1, s);
+    launch_mur(c, 2, s);
+    launch_post(c, FDTD_KIND_V, step, true, s);
+  }
+  launch_dft(c, FDTD_KIND_V, step, s);
+  if (multi) HIPCK(c, hipEventRecord(c->ev_E, s));
+  return FDTD_OK;
+}
+
+static int phase_H(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
+  HIPCK(c, hipSetDevice(c->d.device));
+  const int nk = c->d.nk;
+  const long long step = c->step;
+  hipStream_t s = c->stream;
+  if (pe) HIPCK(c, hipEventRecord(pe->h0[n], s));
+  const bool split = multi && c->d.rank < c->d.world - 1;
+  launch_update_H(c, 0, split ? nk - 1 : nk, step, fused, s);
+  if (pe) HIPCK(c, hipEventRecord(pe->h1[n], s));
+  if (c->haloE_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloE, 0)); c->haloE_pending = false; }
+  if (split && !c->comm && c->link_hi && c->link_hi->haloH_issued) HIPCK(c, hipStreamWaitEvent(s, c->link_hi->ev_haloH, 0));
+  if (split) launch_update_H(c, nk - 1, nk, step, false, s);
+  if (!fused) launch_post(c, FDTD_KIND_I, step, false, s);
+  launch_dft(c, FDTD_KIND_I, step, s);
+  if (multi) HIPCK(c, hipEventRecord(c->ev_H, s));
+  return FDTD_OK;
+}
+
+static int step_loop_fused(fdtd_ctx* c, int nsteps, struct ProfEvents* pe);
+
 static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   const unsigned kmode = c->d.flags & FDTD_FLAG_KERNEL_MASK;
   if (kmode == FDTD_FLAG_KERNEL_FUSED && !fused_eligible(c))
     return fdtd_fail(c, FDTD_E_UNSUPPORTED, "fused kernel needs a single slab, a class operator and no Mur faces");
   // AUTO currently resolves to the two-pass kernels (faster on MI355X as measured, profiles/r01); the
-  // one-pass kernel is opt-in until its CPML path is restructured.
+  // one-pass kernel is opt-in until it shares neighbours through LDS.
   if (kmode == FDTD_FLAG_KERNEL_FUSED) return step_loop_fused(c, nsteps, pe);
-  const int nk = c->d.nk;
   const bool multi = c->d.world > 1;
-  if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_comm_init (RCCL) or drive fdtd_half_step + fdtd_halo_*");
+  if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
   const bool fused = !c->any_mur;
-  hipStream_t s = c->stream;
   for (int n = 0; n < nsteps; ++n) {
-    const long long step = c->step;
-    // ---- E half-step: interior planes first, plane 0 (needs the H ghost from below) last ----
-    launch_mur(c, 0, s);
-    if (pe) HIPCK(c, hipEventRecord(pe->e0[n], s));
-    if (multi && c->d.rank > 0) {
-      launch_update_E(c, 1, nk, step, fused, true, s);
-      if (pe) HIPCK(c, hipEventRecord(pe->e1[n], s));
-      if (c->haloH_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloH, 0)); c->haloH_pending = false; }
-      launch_update_E(c, 0, 1, step, fused, false, s);
-    } else {
-      launch_update_E(c, 0, nk, step, fused, true, s);
-      if (pe) HIPCK(c, hipEventRecord(pe->e1[n], s));
-      if (c->haloH_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloH, 0)); c->haloH_pending = false; }
-    }
-    if (!fused) {
-      launch_mur(c, 1, s);
-      launch_mur(c, 2, s);
-      launch_post(c, FDTD_KIND_V, step, true, s);
-    }
-    launch_dft(c, FDTD_KIND_V, step, s);
-    if (multi) { int r = exchange(c, FDTD_HALO_E_DOWN); if (r) return r; }
-    // ---- H half-step: all planes but the top one overlap the E halo; the top plane goes last ----
-    if (pe) HIPCK(c, hipEventRecord(pe->h0[n], s));
-    if (multi && c->d.rank < c->d.world - 1) {
-      launch_update_H(c, 0, nk - 1, step, fused, s);
-      if (pe) HIPCK(c, hipEventRecord(pe->h1[n], s));
-      if (c->haloE_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloE, 0)); c->haloE_pending = false; }
-      launch_update_H(c, nk - 1, nk, step, false, s);
-    } else {
-      launch_update_H(c, 0, nk, step, fused, s);
-      if (pe) HIPCK(c, hipEventRecord(pe->h1[n], s));
-      if (c->haloE_pending) { HIPCK(c, hipStreamWaitEvent(s, c->ev_haloE, 0)); c->haloE_pending = false; }
-    }
-    if (!fused) launch_post(c, FDTD_KIND_I, step, false, s);
-    launch_dft(c, FDTD_KIND_I, step, s);
-    if (multi) { int r = exchange(c, FDTD_HALO_H_UP); if (r) return r; }
+    int r = phase_E(c, multi, fused, pe, n);
+    if (r) return r;
+    if (multi && (r = exchange(c, FDTD_HALO_E_DOWN))) return r;
+    if ((r = phase_H(c, multi, fused, pe, n))) return r;
+    if (multi && (r = exchange(c, FDTD_HALO_H_UP))) return r;
     c->step++;
   }
-  if (fused && nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, s);   // flush the last step's I-probes
+  if (fused && nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);   // flush the last step's I-probes
   HIPCK(c, hipGetLastError());
   return FDTD_OK;
 }
@@ -827,6 +872,59 @@ int fdtd_halo_put(fdtd_ctx* c, int which, const float* buf) {
     HIPCK(c, plane_h2d(c, c->p.V[0] + c->nloc, buf));
     HIPCK(c, plane_h2d(c, c->p.V[1] + c->nloc, buf + hp));
   } else return fdtd_fail(c, FDTD_E_ARG, "bad halo id");
+  return FDTD_OK;
+}
+
+// ---- in-process transport: several slabs driven by one host thread ---------------------------------------
+int fdtd_link(fdtd_ctx* lower, fdtd_ctx* upper) {
+  if (!lower || !upper) return FDTD_E_ARG;
+  if (lower->d.world != upper->d.world || upper->d.rank != lower->d.rank + 1 || lower->d.k0 + lower->d.nk != upper->d.k0 ||
+      lower->d.nx != upper->d.nx || lower->d.ny != upper->d.ny)
+    return fdtd_fail(lower, FDTD_E_ARG, "fdtd_link: contexts are not adjacent slabs of one grid");
+  if (lower->d.device != upper->d.device) {
+    int can = 0;
+    HIPCK(lower, hipDeviceCanAccessPeer(&can, lower->d.device, upper->d.device));
+    if (can) {
+      hipSetDevice(lower->d.device); hipDeviceEnablePeerAccess(upper->d.device, 0);
+      hipSetDevice(upper->d.device); hipDeviceEnablePeerAccess(lower->d.device, 0);
+      (void)hipGetLastError();   // "already enabled" is fine
+    }
+  }
+  lower->link_hi = upper; upper->link_lo = lower;
+  return FDTD_OK;
+}
+
+int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
+  if (!ctxs || n < 1) return FDTD_E_ARG;
+  for (int r = 0; r < n; ++r) {
+    fdtd_ctx* c = ctxs[r];
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (c->d.world != n || c->d.rank != r || c->comm) return fdtd_fail(c, FDTD_E_ARG, "fdtd_run_linked: contexts must be ranks 0..n-1 of a world of n without an RCCL communicator");
+    if ((r > 0 && c->link_lo != ctxs[r - 1]) || (r < n - 1 && c->link_hi != ctxs[r + 1])) return fdtd_fail(c, FDTD_E_STATE, "fdtd_run_linked: call fdtd_link on every adjacent pair first");
+    if ((c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_FUSED) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "fused kernel is single-slab");
+  }
+  const bool multi = n > 1;
+  for (int s = 0; s < nsteps; ++s) {
+    int rc;
+    for (int r = 0; r < n; ++r) if ((rc = phase_E(ctxs[r], multi, !ctxs[r]->any_mur, nullptr, 0))) return rc;
+    if (multi) for (int r = 0; r < n; ++r) { if ((rc = exchange(ctxs[r], FDTD_HALO_E_DOWN))) return rc; ctxs[r]->haloE_issued = true; }
+    for (int r = 0; r < n; ++r) if ((rc = phase_H(ctxs[r], multi, !ctxs[r]->any_mur, nullptr, 0))) return rc;
+    if (multi) for (int r = 0; r < n; ++r) { if ((rc = exchange(ctxs[r], FDTD_HALO_H_UP))) return rc; ctxs[r]->haloH_issued = true; }
+    for (int r = 0; r < n; ++r) ctxs[r]->step++;
+  }
+  for (int r = 0; r < n; ++r) {
+    fdtd_ctx* c = ctxs[r];
+    HIPCK(c, hipSetDevice(c->d.device));
+    if (!c->any_mur && nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);
+    HIPCK(c, hipGetLastError());
+  }
+  for (int r = 0; r < n; ++r) {
+    fdtd_ctx* c = ctxs[r];
+    HIPCK(c, hipSetDevice(c->d.device));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipStreamSynchronize(c->comm_stream));
+  }
   return FDTD_OK;
 }
 

@@ -99,6 +99,9 @@ struct fdtd_ctx {
   hipEvent_t ev_E = nullptr, ev_H = nullptr, ev_haloE = nullptr, ev_haloH = nullptr;
   bool haloE_pending = false, haloH_pending = false;
   void* comm = nullptr;          // ncclComm_t
+  fdtd_ctx* link_lo = nullptr;   // in-process neighbours (fdtd_link)
+  fdtd_ctx* link_hi = nullptr;
+  bool haloE_issued = false, haloH_issued = false;
   bool tables_dirty = true;
   std::string err;
 };

@@ -166,6 +166,11 @@ int fdtd_energy(fdtd_ctx* ctx, double sums[2]);
  *     128 bytes to every rank (e.g. torch.distributed broadcast), every rank calls comm_init. */
 int fdtd_comm_unique_id(void* out128);
 int fdtd_comm_init(fdtd_ctx* ctx, const void* uid128);
+/* (a') Several slabs inside ONE process (one host thread driving several GPUs, or several slabs on one GPU):
+ *      link adjacent contexts, then step them together; halos move by peer copies on the communication
+ *      streams with the same overlapped schedule as the RCCL path. ctxs[r] must be rank r of a world of n. */
+int fdtd_link(fdtd_ctx* lower, fdtd_ctx* upper);
+int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps);
 /* (b) External transport (MPI, gloo, ...): one half-step at a time, halos through host buffers.
  *     buf: [2][ny][nx] floats = the two tangential components (x then y) of one plane. */
 int fdtd_half_step(fdtd_ctx* ctx, int phase);

@@ -582,6 +582,25 @@ int fdtd_energy(fdtd_ctx* c, double sums[2]) {
   return FDTD_OK;
 }
 
+/* in-process multi-slab run: the oracle steps the slabs in lock step with direct ghost copies */
+int fdtd_link(fdtd_ctx* lower, fdtd_ctx* upper) {
+  if (!lower || !upper || upper->d.rank != lower->d.rank + 1 || lower->d.k0 + lower->d.nk != upper->d.k0) return fail(lower, FDTD_E_ARG, "not adjacent slabs");
+  return FDTD_OK;
+}
+
+int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
+  if (!ctxs || n < 1) return FDTD_E_ARG;
+  float* buf = (float*)malloc(2 * ctxs[0]->plane * sizeof(float));
+  for (int s = 0; s < nsteps; ++s) {
+    for (int r = 0; r < n; ++r) { int rc = fdtd_half_step(ctxs[r], FDTD_PHASE_E); if (rc) { free(buf); return rc; } }
+    for (int r = 0; r + 1 < n; ++r) { fdtd_halo_get(ctxs[r + 1], FDTD_HALO_E_DOWN, buf); fdtd_halo_put(ctxs[r], FDTD_HALO_E_DOWN, buf); }
+    for (int r = 0; r < n; ++r) { int rc = fdtd_half_step(ctxs[r], FDTD_PHASE_H); if (rc) { free(buf); return rc; } }
+    for (int r = 0; r + 1 < n; ++r) { fdtd_halo_get(ctxs[r], FDTD_HALO_H_UP, buf); fdtd_halo_put(ctxs[r + 1], FDTD_HALO_H_UP, buf); }
+  }
+  free(buf);
+  return FDTD_OK;
+}
+
 int fdtd_comm_unique_id(void* out128) { (void)out128; return fail(NULL, FDTD_E_UNSUPPORTED, "oracle has no RCCL transport"); }
 int fdtd_comm_init(fdtd_ctx* c, const void* uid) { (void)uid; return fail(c, FDTD_E_UNSUPPORTED, "oracle has no RCCL transport"); }
 

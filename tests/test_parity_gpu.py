@@ -155,6 +155,29 @@ def test_two_slabs_equal_one_slab(hip_lib):
     assert rel_l2(u2, u1) < 1e-12
 
 
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_linked_slabs_overlapped_schedule(hip_lib, world):
+    """The multi-rank step schedule of the RCCL path (interior planes first, dependent boundary plane after
+    the halo event, probes/sources fused into the split launches) driven in-process: `world` slabs on one
+    GPU with peer copies instead of ncclSend/ncclRecv must reproduce the single-slab run bit for bit."""
+    capi = pkg("_capi")
+    s1 = patch_sim(56, 52, 34, nr_ts=260)
+    e1 = s1.build(hip_lib)
+    e1.run(260)
+    sims = [patch_sim(56, 52, 34, nr_ts=260) for _ in range(world)]
+    engs = [s.build(hip_lib, rank=r, world=world) for r, s in enumerate(sims)]
+    for n in (1, 100, 159):
+        capi.run_linked(engs, n)
+    f2 = np.concatenate([e.fields() for e in engs], axis=2)
+    assert np.array_equal(e1.fields().view(np.uint32), f2.view(np.uint32))
+    u1, i1 = s1.port_series()[0]
+    u2 = sum(s.port_series()[0][0] for s in sims)
+    i2 = sum(s.port_series()[0][1] for s in sims)
+    assert rel_l2(u2, u1) < 1e-12 and rel_l2(i2, i1) < 1e-12
+    for a, *parts in zip(s1.nf2ff_boxes(), *[s.nf2ff_boxes() for s in sims]):
+        assert rel_l2(sum(parts), a) < 1e-12
+
+
 def test_rccl_single_rank_comm(hip_lib):
     """World of one: the RCCL communicator initialises and the step loop runs through it."""
     capi = pkg("_capi")
