@@ -72,7 +72,9 @@ enum {
   FDTD_FLAG_KERNEL_DIRECT = 1,   /* two-pass leapfrog: one E launch + one H launch per step */
   FDTD_FLAG_KERNEL_FUSED  = 2,   /* one-pass leapfrog (E+H in one launch, ping-pong buffers); error if not eligible */
   FDTD_FLAG_KERNEL_MASK   = 0xF,
-  FDTD_FLAG_NO_GRAPH      = 0x10 /* do not capture the step loop into a hipGraph */
+  FDTD_FLAG_NO_GRAPH      = 0x10, /* reserved */
+  FDTD_FLAG_OVERLAP_ON    = 0x20, /* multi-slab: split sweeps into interior + halo-dependent plane (the default) */
+  FDTD_FLAG_OVERLAP_OFF   = 0x40  /* multi-slab: one launch per sweep, after the halo has arrived */
 };
 
 typedef struct fdtd_ctx fdtd_ctx;

@@ -155,8 +155,9 @@ def test_two_slabs_equal_one_slab(hip_lib):
     assert rel_l2(u2, u1) < 1e-12
 
 
+@pytest.mark.parametrize("overlap", ["split", "nosplit"])
 @pytest.mark.parametrize("world", [2, 3, 5])
-def test_linked_slabs_overlapped_schedule(hip_lib, world):
+def test_linked_slabs_overlapped_schedule(hip_lib, world, overlap):
     """The multi-rank step schedule of the RCCL path (interior planes first, dependent boundary plane after
     the halo event, probes/sources fused into the split launches) driven in-process: `world` slabs on one
     GPU with peer copies instead of ncclSend/ncclRecv must reproduce the single-slab run bit for bit."""
@@ -165,7 +166,8 @@ def test_linked_slabs_overlapped_schedule(hip_lib, world):
     e1 = s1.build(hip_lib)
     e1.run(260)
     sims = [patch_sim(56, 52, 34, nr_ts=260) for _ in range(world)]
-    engs = [s.build(hip_lib, rank=r, world=world) for r, s in enumerate(sims)]
+    flag = capi.FLAG_OVERLAP_ON if overlap == "split" else capi.FLAG_OVERLAP_OFF
+    engs = [s.build(hip_lib, rank=r, world=world, flags=flag) for r, s in enumerate(sims)]
     for n in (1, 100, 159):
         capi.run_linked(engs, n)
     f2 = np.concatenate([e.fields() for e in engs], axis=2)
