@@ -54,13 +54,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FDTD_BENCH_FORCE_DEVICE") is not None:      # debugging aid: several ranks on one GPU
+        local_rank = int(os.environ["FDTD_BENCH_FORCE_DEVICE"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("FDTD_BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     capi = importlib.import_module(PKG + "._capi")
     wl = importlib.import_module(PKG + ".workloads")
@@ -75,10 +81,18 @@ def main():
                           nr_ts=nts_total, nf2ff_freqs=[w.f0], use_classes=not args.raw_operator)
     flags = {"auto": capi.FLAG_KERNEL_AUTO, "direct": capi.FLAG_KERNEL_DIRECT, "fused": capi.FLAG_KERNEL_FUSED}[args.kernel]
     eng = sim.build(hip, rank=rank, world=world, device=local_rank, flags=flags)
+    comm = None
     if world > 1:
-        uid = [capi.comm_unique_id(hip) if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(uid[0])
+        # RCCL halo exchange inside the library; if the communicator cannot be created on this node every
+        # rank falls back (together) to the host transport so that the run still produces a valid number
+        comm = importlib.import_module(PKG + ".distributed").SlabComm(transport="auto")
+        comm.attach(sim)
+
+    def run_steps(n):
+        if sim.external_transport is not None:
+            sim.external_transport.run_steps(eng, n)
+        else:
+            eng.run(n)
 
     def barrier():
         torch.cuda.synchronize()
@@ -88,15 +102,15 @@ def main():
 
     tps = args.ts_per_step
     for _ in range(args.warmup):
-        eng.run(tps)
+        run_steps(tps)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.run(tps)
+        run_steps(tps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -106,7 +120,10 @@ def main():
 
     # roofline of the dominant kernel (E half-step == H half-step in algorithmic bytes): HIP events on
     # the engine's own stream around every main-kernel launch, over a second pass of the same length.
-    prof = eng.run_profiled(min(timesteps, 2000))
+    if sim.external_transport is not None:      # host transport: no in-library step loop to profile
+        prof = capi.FdtdProfile(ms_total=elapsed * 1e3, ms_update_e=float("nan"), ms_update_h=float("nan"), steps=timesteps)
+    else:
+        prof = eng.run_profiled(min(timesteps, 2000))
     own_cells = eng.nk * eng.ny * eng.nx
     algo_bytes = ALGO_BYTES_PER_CELL_HALFSTEP * own_cells
     ms_e, ms_h = prof.ms_update_e, prof.ms_update_h
@@ -115,12 +132,16 @@ def main():
     else:
         dom = "update_E" if ms_e >= ms_h else "update_H"
         ms_dom = max(ms_e, ms_h)
-    achieved = algo_bytes / (ms_dom * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload, dom, world),
-                "kernel": dom, "ms_update_E": round(ms_e, 5), "ms_update_H": round(ms_h, 5),
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "ms_per_timestep_profiled": round(prof.ms_total / prof.steps, 5)}
+    if ms_dom == ms_dom and ms_dom > 0:
+        achieved = algo_bytes / (ms_dom * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload, dom, world),
+                    "kernel": dom, "ms_update_E": round(ms_e, 5), "ms_update_H": round(ms_h, 5),
+                    "algorithmic_bytes_per_launch": algo_bytes,
+                    "ms_per_timestep_profiled": round(prof.ms_total / prof.steps, 5)}
+    else:               # host halo transport: kernels are launched one half-step at a time, nothing to profile
+        roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                    "traffic": None, "kernel": dom, "algorithmic_bytes_per_launch": algo_bytes}
     finite = bool(np.isfinite(eng.get_field(0, 2)).all())
 
     cpu = None
@@ -139,7 +160,7 @@ def main():
                                    f"{SCENES.get(args.workload, 'patch')}, CPML-{args.cpml_cells}, "
                                    f"{len(vox.ports)} lumped port(s), NF2FF DFT surfaces",
                        "cells": ncells, "timesteps_per_step": tps, "operator": sim.operator_form,
-                       "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
+                       "parallelism": f"z-slab x{world}, halo transport {comm.transport_used}" if world > 1 else "single GPU",
                        "fields_finite": finite},
             "roofline": roofline,
         }

@@ -31,6 +31,8 @@ class SlabComm:
         self.backend = dist.get_backend()
         self.transport = transport
         self.sim = None
+        self.transport_used = None
+        self.rccl_error = None
 
     # -- tensors on the right device for the process group ------------------------------------------
     def _to_t(self, a: np.ndarray):
@@ -60,10 +62,18 @@ class SlabComm:
         if use_rccl:
             uid = [_capi.comm_unique_id(eng.lib) if self.rank == 0 else None]
             self.dist.broadcast_object_list(uid, src=0)
-            eng.comm_init(uid[0])
-            sim.external_transport = None
-        else:
-            sim.external_transport = self
+            ok = 1.0
+            try:
+                eng.comm_init(uid[0])
+            except _capi.FdtdError as exc:      # e.g. an RCCL set-up problem on this node
+                ok, self.rccl_error = 0.0, str(exc)
+            # every rank must take the same path: fall back to the host transport together
+            if float(self.allreduce(np.array([ok]))[0]) == self.world:
+                sim.external_transport = None
+                self.transport_used = "rccl"
+                return
+        sim.external_transport = self
+        self.transport_used = "host"
 
     # -- host transport: one exchange after each half-step ------------------------------------------
     def exchange(self, eng, which: int):
