@@ -3,6 +3,7 @@
 #include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -153,7 +154,11 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   // six field arrays + class bytes vs the 256 MiB Infinity Cache
   p.nt = ((size_t)c->nloc * (6 * sizeof(float) + 1) > (size_t)200 << 20) ? 1 : 0;
   choose_tiling(c);
-  p.src_rng = nullptr; p.src_ids = nullptr; p.src_rng2 = nullptr; p.src_ids2 = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
+  if (const char* ts = getenv("FDTD_TILE_SHAPE")) {
+    const int v = (int)strtol(ts, nullptr, 16);
+    if (v == 0x88 || v == 0x48 || v == 0x84 || v == 0x44) c->tile_shape = v;
+  }
+  p.src_rng = nullptr; p.src_ids = nullptr; p.src_rng2 = nullptr; p.src_ids2 = nullptr; p.src_rng3 = nullptr; p.src_ids3 = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
   p.sig = c->sig; p.nsig = 0;
   p.probes = c->d_probe; p.nprobe = 0; p.max_steps = d->max_steps;
   *out = c;
@@ -643,6 +648,35 @@ static int ensure_fused(fdtd_ctx* c) {
   if (max_len > FDTD_BLOCK)
     return fdtd_fail(c, FDTD_E_UNSUPPORTED, "fused kernel: %d source edges in one strip-plane (limit %d)", max_len, FDTD_BLOCK);
   c->p.src_rng2 = c->src_rng2; c->p.src_ids2 = c->src_ids2;
+  {   // per-tile source lists for the LDS-tile kernel
+    int ntx, nty, ntz;
+    tile_counts(c, ntx, nty, ntz);
+    std::vector<std::vector<int>> lists((size_t)ntx * nty * ntz);
+    std::vector<int> tl;
+    for (size_t e = 0; e < c->h_src_off.size(); ++e) {
+      const int off = c->h_src_off[e];
+      const int k = off / c->plane, j = (off - k * c->plane) / c->P, i = off - k * c->plane - j * c->P;
+      tl.clear();
+      tiles_of_cell(c, i / 4, j, k, tl);
+      for (int t : tl) lists[t].push_back((int)e);
+    }
+    std::vector<int2> rng(lists.size());
+    std::vector<int> ids;
+    int mx = 0;
+    for (size_t q = 0; q < lists.size(); ++q) {
+      rng[q].x = (int)ids.size();
+      ids.insert(ids.end(), lists[q].begin(), lists[q].end());
+      rng[q].y = (int)ids.size();
+      mx = std::max(mx, (int)lists[q].size());
+    }
+    if (mx > FDTD_BLOCK) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "tile kernel: %d source edges in one tile (limit %d)", mx, FDTD_BLOCK);
+    hipFree(c->src_rng3); hipFree(c->src_ids3); c->src_rng3 = nullptr; c->src_ids3 = nullptr;
+    HIPCK(c, hipMalloc(&c->src_rng3, rng.size() * sizeof(int2)));
+    HIPCK(c, hipMemcpy(c->src_rng3, rng.data(), rng.size() * sizeof(int2), hipMemcpyHostToDevice));
+    HIPCK(c, hipMalloc(&c->src_ids3, std::max<size_t>(ids.size(), 1) * sizeof(int)));
+    if (!ids.empty()) HIPCK(c, hipMemcpy(c->src_ids3, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->p.src_rng3 = c->src_rng3; c->p.src_ids3 = c->src_ids3;
+  }
   c->fused_ready = true;
   return FDTD_OK;
 }
@@ -729,11 +763,11 @@ static int step_loop_fused(fdtd_ctx* c, int nsteps, struct ProfEvents* pe);
 
 static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   const unsigned kmode = c->d.flags & FDTD_FLAG_KERNEL_MASK;
-  if (kmode == FDTD_FLAG_KERNEL_FUSED && !fused_eligible(c))
+  if ((kmode == FDTD_FLAG_KERNEL_FUSED || kmode == FDTD_FLAG_KERNEL_TILE) && !fused_eligible(c))
     return fdtd_fail(c, FDTD_E_UNSUPPORTED, "fused kernel needs a single slab, a class operator and no Mur faces");
   // AUTO currently resolves to the two-pass kernels (faster on MI355X as measured, profiles/r01); the
   // one-pass kernel is opt-in until it shares neighbours through LDS.
-  if (kmode == FDTD_FLAG_KERNEL_FUSED) return step_loop_fused(c, nsteps, pe);
+  if (kmode == FDTD_FLAG_KERNEL_FUSED || kmode == FDTD_FLAG_KERNEL_TILE) return step_loop_fused(c, nsteps, pe);
   const bool multi = c->d.world > 1;
   if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
   const bool fused = !c->any_mur;
@@ -759,7 +793,8 @@ static int step_loop_fused(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   for (int n = 0; n < nsteps; ++n) {
     const long long step = c->step;
     if (pe) HIPCK(c, hipEventRecord(pe->e0[n], s));
-    launch_step_fused(c, step, true, s);
+    if ((c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_TILE) launch_step_tile(c, step, true, s);
+    else launch_step_fused(c, step, true, s);
     if (pe) { HIPCK(c, hipEventRecord(pe->e1[n], s)); HIPCK(c, hipEventRecord(pe->h0[n], s)); HIPCK(c, hipEventRecord(pe->h1[n], s)); }
     for (int q = 0; q < 3; ++q) { std::swap(c->p.V[q], c->p.Vn[q]); std::swap(c->p.I[q], c->p.In[q]); }
     for (int comp = 0; comp < 3; ++comp)
@@ -813,7 +848,7 @@ int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
       hipEventElapsedTime(&ms, pe.h0[n], pe.h1[n]); sh += ms;
     }
     out->ms_update_e = se / nsteps; out->ms_update_h = sh / nsteps;
-    out->fused = ((c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_FUSED) ? 1 : 0;
+    out->fused = ((c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_FUSED || (c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_TILE) ? 1 : 0;
     out->launches_e = out->launches_h = nsteps;
   }
   for (auto* v : {&pe.e0, &pe.e1, &pe.h0, &pe.h1}) for (auto e : *v) hipEventDestroy(e);
@@ -926,6 +961,7 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
     if (c->d.world != n || c->d.rank != r || c->comm) return fdtd_fail(c, FDTD_E_ARG, "fdtd_run_linked: contexts must be ranks 0..n-1 of a world of n without an RCCL communicator");
     if ((r > 0 && c->link_lo != ctxs[r - 1]) || (r < n - 1 && c->link_hi != ctxs[r + 1])) return fdtd_fail(c, FDTD_E_STATE, "fdtd_run_linked: call fdtd_link on every adjacent pair first");
     if ((c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_FUSED) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "fused kernel is single-slab");
+    if ((c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_TILE) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "tile kernel is single-slab");
   }
   const bool multi = n > 1;
   for (int s = 0; s < nsteps; ++s) {

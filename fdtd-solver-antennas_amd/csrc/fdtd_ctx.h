@@ -38,6 +38,8 @@ struct DevParams {
   float* psiE[3][2];
   float* psiH[3][2];
   float* psiEn[3][2];        // fused kernel: next-step psi_E (ping-pong); psi_H is updated in place
+  const int2* src_rng3;      // LDS-tile kernel: sources computed by the threads of tile id
+  const int* src_ids3;
   const int2* src_rng2;      // fused kernel tiling: sources in rows [j0, j0+rows] x planes [k, k+1] of a strip-plane
   const int* src_ids2;
   // launch tiling: a block = 256 threads = 1024 consecutive x-cells of one strip of `tys` rows in one plane
@@ -66,7 +68,9 @@ struct fdtd_ctx {
   float* fieldbase2[6] = {};     // ping-pong partner (fused kernel), allocated on first fused run
   float* psi2[6] = {};           // ping-pong partner of the six psi_E arrays
   int2* src_rng2 = nullptr; int* src_ids2 = nullptr;
+  int2* src_rng3 = nullptr; int* src_ids3 = nullptr;
   bool fused_ready = false;
+  int tile_shape = 0x88;         // LDS-tile kernel: (TY << 4) | TZ threads; $FDTD_TILE_SHAPE = 88 | 48 | 84 | 44
   size_t psi_bytes[3] = {64, 64, 64};
   float *vv = nullptr, *vi = nullptr, *ii = nullptr, *iv = nullptr;
   uint8_t* ecls = nullptr;
@@ -125,5 +129,9 @@ void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);
 // fused.hip: one launch = E half-step + H half-step of all owned planes, current -> next buffers
 void launch_step_fused(fdtd_ctx* c, long long step, bool probe_block, hipStream_t s);
 void choose_tiling_fused(fdtd_ctx* c);
+// tile.hip: one-pass kernel with an LDS-shared E tile
+void launch_step_tile(fdtd_ctx* c, long long step, bool probe_block, hipStream_t s);
+void tile_counts(const fdtd_ctx* c, int& ntx, int& nty, int& ntz);
+void tiles_of_cell(const fdtd_ctx* c, int gx, int j, int k, std::vector<int>& out);
 void launch_energy(fdtd_ctx* c, hipStream_t s);
 void choose_tiling(fdtd_ctx* c);
