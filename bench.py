@@ -223,13 +223,17 @@ def cpu_baseline(capi, simm, w, vox, args):
     for kind in (0, 1):        # non-zero start: avoids x86 denormal stalls of the all-zero initial state
         for c in range(3):
             e.set_field(kind, c, (1e-3 * rng.standard_normal(e.local_shape)).astype(np.float32))
-    t0 = time.perf_counter()
-    e.run(8)                   # pilot: sizes the sample to ~12 s of CPU work
-    pilot = (time.perf_counter() - t0) / 8
-    steps = args.cpu_steps or int(min(nr_cap - 16, max(10, 12.0 / max(pilot, 1e-6))))
-    t0 = time.perf_counter()
-    e.run(steps)
-    dt = time.perf_counter() - t0
+    e.run(8)                   # untimed: first touch of the arrays, thread start-up
+    steps, dt, chunk = 0, 0.0, 50
+    while dt < 10.0 and steps + chunk < nr_cap - 16:      # bounded sample: ~10 s of CPU work
+        t0 = time.perf_counter()
+        e.run(chunk)
+        dt += time.perf_counter() - t0
+        steps += chunk
+    if args.cpu_steps:
+        t0 = time.perf_counter()
+        e.run(args.cpu_steps)
+        dt, steps = time.perf_counter() - t0, args.cpu_steps
     return {"value": round(w.grid.ncells * steps / dt / 1e6, 1), "unit": "Mcells/s", "cores": cores,
             "kind": "port",
             "sample": f"{steps} timesteps of the same {w.grid.shape[0]}x{w.grid.shape[1]}x{w.grid.shape[2]} workload "
