@@ -15,7 +15,9 @@
 #define FDTD_MAX_PROBES 64
 #define FDTD_MAX_BOXES 64
 #ifndef FDTD_BLOCK
+#ifndef FDTD_BLOCK
 #define FDTD_BLOCK 256
+#endif
 #endif
 
 struct DevParams {
