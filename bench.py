@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--workload", default="NS")
     ap.add_argument("--ts-per-step", type=int, default=100)
     ap.add_argument("--cpml-cells", type=int, default=10)
-    ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "fused", "tile"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "fused", "tile", "march"])
     ap.add_argument("--raw-operator", action="store_true", help="stream 12 coefficient arrays instead of class bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle timesteps for the cpu_baseline leg (0 = auto)")
@@ -79,7 +79,7 @@ def main():
     nts_total = (args.steps + args.warmup) * args.ts_per_step * 2 + 8
     sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=args.cpml_cells,
                           nr_ts=nts_total, nf2ff_freqs=[w.f0], use_classes=not args.raw_operator)
-    flags = {"auto": capi.FLAG_KERNEL_AUTO, "direct": capi.FLAG_KERNEL_DIRECT, "fused": capi.FLAG_KERNEL_FUSED, "tile": capi.FLAG_KERNEL_TILE}[args.kernel]
+    flags = {"auto": capi.FLAG_KERNEL_AUTO, "direct": capi.FLAG_KERNEL_DIRECT, "fused": capi.FLAG_KERNEL_FUSED, "tile": capi.FLAG_KERNEL_TILE, "march": capi.FLAG_KERNEL_MARCH}[args.kernel]
     eng = sim.build(hip, rank=rank, world=world, device=local_rank, flags=flags)
     comm = None
     if world > 1:

@@ -158,7 +158,11 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
     const int v = (int)strtol(ts, nullptr, 16);
     if (v == 0x88 || v == 0x48 || v == 0x84 || v == 0x44) c->tile_shape = v;
   }
-  p.src_rng = nullptr; p.src_ids = nullptr; p.src_rng2 = nullptr; p.src_ids2 = nullptr; p.src_rng3 = nullptr; p.src_ids3 = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
+  if (const char* kc = getenv("FDTD_MARCH_KC")) {
+    const int v = atoi(kc);
+    if (v >= 1 && v <= 4096) c->march_kc = v;
+  }
+  p.src_rng = nullptr; p.src_ids = nullptr; p.src_rng2 = nullptr; p.src_ids2 = nullptr; p.src_rng3 = nullptr; p.src_ids3 = nullptr; p.src_rng4 = nullptr; p.src_ids4 = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
   p.sig = c->sig; p.nsig = 0;
   p.probes = c->d_probe; p.nprobe = 0; p.max_steps = d->max_steps;
   *out = c;
@@ -183,6 +187,7 @@ void fdtd_destroy(fdtd_ctx* c) {
   for (int b = 0; b < c->nbox; ++b) hipFree(c->box[b].acc);
   hipFree(c->d_probe); hipFree(c->d_box); hipFree(c->tw_v); hipFree(c->tw_i);
   hipFree(c->d_energy); hipFree(c->src_rng); hipFree(c->src_ids); hipFree(c->src_rng2); hipFree(c->src_ids2);
+  hipFree(c->src_rng3); hipFree(c->src_ids3); hipFree(c->src_rng4); hipFree(c->src_ids4);
   for (int n = 0; n < 6; ++n) { hipFree(c->fieldbase2[n]); hipFree(c->psi2[n]); }
   if (c->ev_E) hipEventDestroy(c->ev_E);
   if (c->ev_H) hipEventDestroy(c->ev_H);
@@ -648,16 +653,15 @@ static int ensure_fused(fdtd_ctx* c) {
   if (max_len > FDTD_BLOCK)
     return fdtd_fail(c, FDTD_E_UNSUPPORTED, "fused kernel: %d source edges in one strip-plane (limit %d)", max_len, FDTD_BLOCK);
   c->p.src_rng2 = c->src_rng2; c->p.src_ids2 = c->src_ids2;
-  {   // per-tile source lists for the LDS-tile kernel
-    int ntx, nty, ntz;
-    tile_counts(c, ntx, nty, ntz);
-    std::vector<std::vector<int>> lists((size_t)ntx * nty * ntz);
+  // per-tile source lists (LDS-tile kernel: 3-D tiles; z-marching kernel: tile columns)
+  auto tile_lists = [&](size_t ntiles, auto&& tiles_of, const char* what, int2** d_rng, int** d_ids) -> int {
+    std::vector<std::vector<int>> lists(ntiles);
     std::vector<int> tl;
     for (size_t e = 0; e < c->h_src_off.size(); ++e) {
       const int off = c->h_src_off[e];
       const int k = off / c->plane, j = (off - k * c->plane) / c->P, i = off - k * c->plane - j * c->P;
       tl.clear();
-      tiles_of_cell(c, i / 4, j, k, tl);
+      tiles_of(i / 4, j, k, tl);
       for (int t : tl) lists[t].push_back((int)e);
     }
     std::vector<int2> rng(lists.size());
@@ -669,13 +673,24 @@ static int ensure_fused(fdtd_ctx* c) {
       rng[q].y = (int)ids.size();
       mx = std::max(mx, (int)lists[q].size());
     }
-    if (mx > FDTD_BLOCK) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "tile kernel: %d source edges in one tile (limit %d)", mx, FDTD_BLOCK);
-    hipFree(c->src_rng3); hipFree(c->src_ids3); c->src_rng3 = nullptr; c->src_ids3 = nullptr;
-    HIPCK(c, hipMalloc(&c->src_rng3, rng.size() * sizeof(int2)));
-    HIPCK(c, hipMemcpy(c->src_rng3, rng.data(), rng.size() * sizeof(int2), hipMemcpyHostToDevice));
-    HIPCK(c, hipMalloc(&c->src_ids3, std::max<size_t>(ids.size(), 1) * sizeof(int)));
-    if (!ids.empty()) HIPCK(c, hipMemcpy(c->src_ids3, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (mx > FDTD_BLOCK) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "%s kernel: %d source edges in one tile (limit %d)", what, mx, FDTD_BLOCK);
+    hipFree(*d_rng); hipFree(*d_ids); *d_rng = nullptr; *d_ids = nullptr;
+    HIPCK(c, hipMalloc(d_rng, rng.size() * sizeof(int2)));
+    HIPCK(c, hipMemcpy(*d_rng, rng.data(), rng.size() * sizeof(int2), hipMemcpyHostToDevice));
+    HIPCK(c, hipMalloc(d_ids, std::max<size_t>(ids.size(), 1) * sizeof(int)));
+    if (!ids.empty()) HIPCK(c, hipMemcpy(*d_ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
+    return FDTD_OK;
+  };
+  {
+    int ntx, nty, ntz, kc, r;
+    tile_counts(c, ntx, nty, ntz);
+    if ((r = tile_lists((size_t)ntx * nty * ntz, [&](int gx, int j, int k, std::vector<int>& o) { tiles_of_cell(c, gx, j, k, o); },
+                        "tile", &c->src_rng3, &c->src_ids3))) return r;
     c->p.src_rng3 = c->src_rng3; c->p.src_ids3 = c->src_ids3;
+    march_counts(c, ntx, nty, ntz, kc);
+    if ((r = tile_lists((size_t)ntx * nty * ntz, [&](int gx, int j, int k, std::vector<int>& o) { march_tiles_of_cell(c, gx, j, k, o); },
+                        "march", &c->src_rng4, &c->src_ids4))) return r;
+    c->p.src_rng4 = c->src_rng4; c->p.src_ids4 = c->src_ids4;
   }
   c->fused_ready = true;
   return FDTD_OK;
@@ -761,13 +776,17 @@ static int phase_H(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
 
 static int step_loop_fused(fdtd_ctx* c, int nsteps, struct ProfEvents* pe);
 
+static bool one_pass_mode(unsigned kmode) {
+  return kmode == FDTD_FLAG_KERNEL_FUSED || kmode == FDTD_FLAG_KERNEL_TILE || kmode == FDTD_FLAG_KERNEL_MARCH;
+}
+
 static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   const unsigned kmode = c->d.flags & FDTD_FLAG_KERNEL_MASK;
-  if ((kmode == FDTD_FLAG_KERNEL_FUSED || kmode == FDTD_FLAG_KERNEL_TILE) && !fused_eligible(c))
+  if (one_pass_mode(kmode) && !fused_eligible(c))
     return fdtd_fail(c, FDTD_E_UNSUPPORTED, "fused kernel needs a single slab, a class operator and no Mur faces");
   // AUTO currently resolves to the two-pass kernels (faster on MI355X as measured, profiles/r01); the
   // one-pass kernel is opt-in until it shares neighbours through LDS.
-  if (kmode == FDTD_FLAG_KERNEL_FUSED || kmode == FDTD_FLAG_KERNEL_TILE) return step_loop_fused(c, nsteps, pe);
+  if (one_pass_mode(kmode)) return step_loop_fused(c, nsteps, pe);
   const bool multi = c->d.world > 1;
   if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
   const bool fused = !c->any_mur;
@@ -793,7 +812,9 @@ static int step_loop_fused(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   for (int n = 0; n < nsteps; ++n) {
     const long long step = c->step;
     if (pe) HIPCK(c, hipEventRecord(pe->e0[n], s));
-    if ((c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_TILE) launch_step_tile(c, step, true, s);
+    const unsigned kmode = c->d.flags & FDTD_FLAG_KERNEL_MASK;
+    if (kmode == FDTD_FLAG_KERNEL_MARCH) launch_step_march(c, step, true, s);
+    else if (kmode == FDTD_FLAG_KERNEL_TILE) launch_step_tile(c, step, true, s);
     else launch_step_fused(c, step, true, s);
     if (pe) { HIPCK(c, hipEventRecord(pe->e1[n], s)); HIPCK(c, hipEventRecord(pe->h0[n], s)); HIPCK(c, hipEventRecord(pe->h1[n], s)); }
     for (int q = 0; q < 3; ++q) { std::swap(c->p.V[q], c->p.Vn[q]); std::swap(c->p.I[q], c->p.In[q]); }
@@ -848,7 +869,7 @@ int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
       hipEventElapsedTime(&ms, pe.h0[n], pe.h1[n]); sh += ms;
     }
     out->ms_update_e = se / nsteps; out->ms_update_h = sh / nsteps;
-    out->fused = ((c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_FUSED || (c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_TILE) ? 1 : 0;
+    out->fused = one_pass_mode(c->d.flags & FDTD_FLAG_KERNEL_MASK) ? 1 : 0;
     out->launches_e = out->launches_h = nsteps;
   }
   for (auto* v : {&pe.e0, &pe.e1, &pe.h0, &pe.h1}) for (auto e : *v) hipEventDestroy(e);
@@ -960,8 +981,7 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
     if (rc) return rc;
     if (c->d.world != n || c->d.rank != r || c->comm) return fdtd_fail(c, FDTD_E_ARG, "fdtd_run_linked: contexts must be ranks 0..n-1 of a world of n without an RCCL communicator");
     if ((r > 0 && c->link_lo != ctxs[r - 1]) || (r < n - 1 && c->link_hi != ctxs[r + 1])) return fdtd_fail(c, FDTD_E_STATE, "fdtd_run_linked: call fdtd_link on every adjacent pair first");
-    if ((c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_FUSED) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "fused kernel is single-slab");
-    if ((c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_TILE) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "tile kernel is single-slab");
+    if (one_pass_mode(c->d.flags & FDTD_FLAG_KERNEL_MASK)) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "one-pass kernels are single-slab");
   }
   const bool multi = n > 1;
   for (int s = 0; s < nsteps; ++s) {

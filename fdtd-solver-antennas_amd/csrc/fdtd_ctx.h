@@ -44,6 +44,8 @@ struct DevParams {
   float* psiEn[3][2];        // fused kernel: next-step psi_E (ping-pong); psi_H is updated in place
   const int2* src_rng3;      // LDS-tile kernel: sources computed by the threads of tile id
   const int* src_ids3;
+  const int2* src_rng4;      // z-marching kernel: sources inside tile column id (xy footprint incl. feeders, planes kb..ke)
+  const int* src_ids4;
   const int2* src_rng2;      // fused kernel tiling: sources in rows [j0, j0+rows] x planes [k, k+1] of a strip-plane
   const int* src_ids2;
   // launch tiling: a block = 256 threads = 1024 consecutive x-cells of one strip of `tys` rows in one plane
@@ -73,6 +75,8 @@ struct fdtd_ctx {
   float* psi2[6] = {};           // ping-pong partner of the six psi_E arrays
   int2* src_rng2 = nullptr; int* src_ids2 = nullptr;
   int2* src_rng3 = nullptr; int* src_ids3 = nullptr;
+  int2* src_rng4 = nullptr; int* src_ids4 = nullptr;
+  int march_kc = 0;              // z-marching kernel: planes per chunk ($FDTD_MARCH_KC, default 10)
   bool fused_ready = false;
   int tile_shape = 0x88;         // LDS-tile kernel: (TY << 4) | TZ threads; $FDTD_TILE_SHAPE = 88 | 48 | 84 | 44
   size_t psi_bytes[3] = {64, 64, 64};
@@ -137,5 +141,9 @@ void choose_tiling_fused(fdtd_ctx* c);
 void launch_step_tile(fdtd_ctx* c, long long step, bool probe_block, hipStream_t s);
 void tile_counts(const fdtd_ctx* c, int& ntx, int& nty, int& ntz);
 void tiles_of_cell(const fdtd_ctx* c, int gx, int j, int k, std::vector<int>& out);
+// march.hip: one-pass kernel, xy tiles marching through z
+void launch_step_march(fdtd_ctx* c, long long step, bool probe_block, hipStream_t s);
+void march_counts(const fdtd_ctx* c, int& ntx, int& nty, int& ntz, int& kc);
+void march_tiles_of_cell(const fdtd_ctx* c, int gx, int j, int k, std::vector<int>& out);
 void launch_energy(fdtd_ctx* c, hipStream_t s);
 void choose_tiling(fdtd_ctx* c);

@@ -72,6 +72,7 @@ enum {
   FDTD_FLAG_KERNEL_DIRECT = 1,   /* two-pass leapfrog: one E launch + one H launch per step */
   FDTD_FLAG_KERNEL_FUSED  = 2,   /* one-pass leapfrog, neighbours recomputed per thread (ping-pong buffers); error if not eligible */
   FDTD_FLAG_KERNEL_TILE   = 3,   /* one-pass leapfrog, neighbours shared through an LDS tile (overlapped 16x8x8 tiling) */
+  FDTD_FLAG_KERNEL_MARCH  = 4,   /* one-pass leapfrog, 16x16 xy tiles marching through z with an LDS-shared E plane */
   FDTD_FLAG_KERNEL_MASK   = 0xF,
   FDTD_FLAG_NO_GRAPH      = 0x10, /* reserved */
   FDTD_FLAG_OVERLAP_ON    = 0x20, /* multi-slab: split sweeps into interior + halo-dependent plane (the default) */

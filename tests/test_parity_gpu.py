@@ -31,7 +31,13 @@ def _run_both(sim_factory, hip_lib, oracle_lib, steps, seed=None, flags=0):
     return out
 
 
-@pytest.mark.parametrize("kernel", ["fused", "tile", "direct"])
+def _kflags(kernel):
+    capi = pkg("_capi")
+    return {"direct": capi.FLAG_KERNEL_DIRECT, "fused": capi.FLAG_KERNEL_FUSED, "tile": capi.FLAG_KERNEL_TILE,
+            "march": capi.FLAG_KERNEL_MARCH}[kernel]
+
+
+@pytest.mark.parametrize("kernel", ["fused", "tile", "march", "direct"])
 @pytest.mark.parametrize("use_classes", [True, False])
 @pytest.mark.parametrize("shape", [(64, 60, 36), (53, 47, 31)])
 def test_fields_bitexact_cpml(hip_lib, oracle_lib, shape, use_classes, kernel):
@@ -40,7 +46,7 @@ def test_fields_bitexact_cpml(hip_lib, oracle_lib, shape, use_classes, kernel):
     capi = pkg("_capi")
     if kernel != "direct" and not use_classes:
         pytest.skip("the one-pass kernels need the class-compressed operator")
-    flags = {"direct": capi.FLAG_KERNEL_DIRECT, "fused": capi.FLAG_KERNEL_FUSED, "tile": capi.FLAG_KERNEL_TILE}[kernel]
+    flags = _kflags(kernel)
     (sh, eh), (so, eo) = _run_both(lambda: patch_sim(*shape, boundary="CPML", cpml_cells=8, nr_ts=300,
                                                      use_classes=use_classes), hip_lib, oracle_lib, 300, seed=1, flags=flags)
     assert eh.backend.startswith("hip") and eo.backend.startswith("oracle")
@@ -90,23 +96,23 @@ def test_fused_flag_rejects_ineligible_scene(hip_lib):
         e.run(2)
 
 
-@pytest.mark.parametrize("kernel", ["fused", "tile"])
+@pytest.mark.parametrize("kernel", ["fused", "tile", "march"])
 def test_fused_no_pml_and_odd_sizes(hip_lib, oracle_lib, kernel):
     """PEC box (no CPML template path), nx not a multiple of 4, sources + probes, one-pass kernels vs oracle."""
     capi = pkg("_capi")
     (sh, eh), (so, eo) = _run_both(lambda: patch_sim(45, 43, 29, boundary="PEC", nr_ts=400, nf2ff=False), hip_lib, oracle_lib, 400,
-                                   flags=capi.FLAG_KERNEL_FUSED if kernel == "fused" else capi.FLAG_KERNEL_TILE)
+                                   flags=_kflags(kernel))
     assert same_values(eh.fields(), eo.fields()) and np.abs(eo.fields()).max() > 0
     assert rel_l2(sh.port_series()[0][0], so.port_series()[0][0]) < 1e-12
 
 
-@pytest.mark.parametrize("kernel", ["fused", "tile", "direct"])
+@pytest.mark.parametrize("kernel", ["fused", "tile", "march", "direct"])
 def test_chunked_runs_and_fused_probes(hip_lib, oracle_lib, kernel):
     """fdtd_run in uneven chunks (probe flush at every call end, sources injected inside the main kernels)
     must give the same series as the oracle's plain loop."""
     capi = pkg("_capi")
     sh, so = patch_sim(48, 44, 32, nr_ts=700), patch_sim(48, 44, 32, nr_ts=700)
-    eh = sh.build(hip_lib, flags={"direct": capi.FLAG_KERNEL_DIRECT, "fused": capi.FLAG_KERNEL_FUSED, "tile": capi.FLAG_KERNEL_TILE}[kernel])
+    eh = sh.build(hip_lib, flags=_kflags(kernel))
     eo = so.build(oracle_lib)
     for n in (1, 2, 97, 250, 349, 1):
         eh.run(n)
