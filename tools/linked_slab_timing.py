@@ -1,5 +1,7 @@
-import sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
+"""Per-step cost of N linked z-slabs driven by one process on ONE GPU (fdtd_link / fdtd_run_linked): the excess over
+world = 1 is the host + launch overhead of the multi-slab schedule."""
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from importlib import import_module as im
 capi = im("fdtd-solver-antennas_amd._capi"); wl = im("fdtd-solver-antennas_amd.workloads"); sc = im("fdtd-solver-antennas_amd.scene"); simm = im("fdtd-solver-antennas_amd.simulation")
 import torch
