@@ -3,7 +3,10 @@
 time-stepped to completion on the MI355X library and on the CPU oracle; reports S11(f) and E/H-plane pattern
 agreement (relative L2) plus both throughputs.  Writes one JSON object to stdout.
 
-    python tools/validate_northstar.py [--steps 12000] [--workload NS]
+    python tests/acceptance_northstar.py [--steps 12000] [--workload NS]
+
+Lives under tests/ because it loads the oracle (test infrastructure); `test_parity_gpu.py::
+test_northstar_acceptance` runs a shorter version of it in the -m gpu suite.
 """
 import argparse
 import ctypes
@@ -24,11 +27,8 @@ def rel_l2(a, b):
     return float(np.linalg.norm(np.ravel(a) - np.ravel(b)) / np.linalg.norm(np.ravel(b)))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=12000)
-    ap.add_argument("--workload", default="NS")
-    args = ap.parse_args()
+def run(steps=12000, workload="NS"):
+    args = argparse.Namespace(steps=steps, workload=workload)
     capi = importlib.import_module(PKG + "._capi")
     wl = importlib.import_module(PKG + ".workloads")
     sc = importlib.import_module(PKG + ".scene")
@@ -70,7 +70,15 @@ def main():
                      "port_u": rel_l2(g[3], c[3]), "port_i": rel_l2(g[4], c[4]), "Dmax": abs(g[2] - c[2]) / c[2]}
     out["tolerance"] = 1e-3
     out["pass"] = all(v < 1e-3 for v in out["rel_l2"].values())
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=12000)
+    ap.add_argument("--workload", default="NS")
+    args = ap.parse_args()
+    print(json.dumps(run(args.steps, args.workload)))
 
 
 if __name__ == "__main__":

@@ -268,3 +268,16 @@ def test_multi_patch_rotated_runs_on_gpu(hip_lib, tmp_path):
     assert np.isfinite(r.intensity).all() and r.intensity.shape == (31, 13)
     series = prep.FDTD.sim.port_series()
     assert len(series) == 2 and all(np.abs(u).max() > 0 and np.abs(i).max() > 0 for u, i in series)
+
+
+def test_northstar_acceptance(hip_lib, oracle_lib):
+    """BASELINE north-star grid (300x300x60, CPML-10, lumped port, NF2FF surfaces) stepped on the HIP library and on
+    the oracle: port series, S11(f), E/H-plane cuts and Dmax within the north-star's 1e-3 relative-L2 tolerance
+    (they are in fact identical to rounding: same fp32 operation order).  3000 of the 12000 steps of the full
+    acceptance run (tests/acceptance_northstar.py; its r01 result is committed under profiles/r01/)."""
+    import acceptance_northstar
+    out = acceptance_northstar.run(steps=3000, workload="NS")
+    assert out["gpu"]["backend"].startswith("hip") and out["cpu_oracle"]["backend"].startswith("oracle")
+    assert out["tolerance"] == 1e-3
+    assert out["pass"], out["rel_l2"]
+    assert max(out["rel_l2"].values()) < 1e-6, out["rel_l2"]
