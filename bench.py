@@ -119,7 +119,9 @@ def main():
     value = ncells * timesteps / elapsed / 1e6
 
     # roofline of the dominant kernel (E half-step == H half-step in algorithmic bytes): HIP events on
-    # the engine's own stream around every main-kernel launch, over a second pass of the same length.
+    # the engine's own stream around every main-kernel launch, over a second pass of the same length; the
+    # interval an event pair measures with NOTHING between (the event packets' own time, calibrated in the same
+    # call) is subtracted, which is what makes the figure agree with rocprofv3's kernel durations.
     if sim.external_transport is not None:      # host transport: no in-library step loop to profile
         prof = capi.FdtdProfile(ms_total=elapsed * 1e3, ms_update_e=float("nan"), ms_update_h=float("nan"), steps=timesteps)
     else:
@@ -138,6 +140,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload, dom, world),
                     "kernel": dom, "ms_update_E": round(ms_e, 5), "ms_update_H": round(ms_h, 5),
                     "algorithmic_bytes_per_launch": algo_bytes,
+                    "ms_event_overhead_subtracted": round(prof.ms_event_overhead, 5),
                     "ms_per_timestep_profiled": round(prof.ms_total / prof.steps, 5)}
     else:               # host halo transport: kernels are launched one half-step at a time, nothing to profile
         roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,

@@ -36,7 +36,7 @@ class FdtdDesc(C.Structure):
 class FdtdProfile(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_update_e", C.c_double), ("ms_update_h", C.c_double),
                 ("launches_e", C.c_int32), ("launches_h", C.c_int32),
-                ("steps", C.c_int32), ("fused", C.c_int32)]
+                ("steps", C.c_int32), ("fused", C.c_int32), ("ms_event_overhead", C.c_double)]
 
 
 FLAG_KERNEL_AUTO, FLAG_KERNEL_DIRECT, FLAG_KERNEL_FUSED, FLAG_KERNEL_TILE, FLAG_NO_GRAPH = 0, 1, 2, 3, 0x10

@@ -868,7 +868,29 @@ int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
       hipEventElapsedTime(&ms, pe.e0[n], pe.e1[n]); se += ms;
       hipEventElapsedTime(&ms, pe.h0[n], pe.h1[n]); sh += ms;
     }
-    out->ms_update_e = se / nsteps; out->ms_update_h = sh / nsteps;
+    // fixed cost of timing ONE launch with an event pair: the same pair with nothing between, same stream (the
+    // event packets' own processing time); subtracted so that the figure is the kernel's begin-to-end duration
+    // as rocprofv3 reports it (an empty kernel there still lasts ~3.6 us, which is real per-launch cost and stays in)
+    double ov = 0.0;
+    {
+      const int reps = 64, lead = 8;     // all pairs queued back to back (steady state, like the step loop), one sync
+      std::vector<hipEvent_t> a(reps + lead), b(reps + lead);
+      for (auto& e : a) hipEventCreate(&e);
+      for (auto& e : b) hipEventCreate(&e);
+      for (int q = 0; q < reps + lead; ++q) {
+        hipEventRecord(a[q], c->stream);
+        hipEventRecord(b[q], c->stream);
+      }
+      hipStreamSynchronize(c->stream);
+      for (int q = lead; q < reps + lead; ++q) { hipEventElapsedTime(&ms, a[q], b[q]); ov += ms; }
+      ov /= reps;
+      for (auto e : a) hipEventDestroy(e);
+      for (auto e : b) hipEventDestroy(e);
+    }
+    out->ms_event_overhead = ov;
+    out->ms_update_e = std::max(0.0, se / nsteps - ov);
+    const bool one_pass = one_pass_mode(c->d.flags & FDTD_FLAG_KERNEL_MASK);
+    out->ms_update_h = one_pass ? 0.0 : std::max(0.0, sh / nsteps - ov);
     out->fused = one_pass_mode(c->d.flags & FDTD_FLAG_KERNEL_MASK) ? 1 : 0;
     out->launches_e = out->launches_h = nsteps;
   }

@@ -93,12 +93,14 @@ typedef struct fdtd_desc {
 
 typedef struct fdtd_profile {
   double ms_total;        /* stream time for the profiled steps, HIP events */
-  double ms_update_e;     /* average duration of one E half-step main kernel launch */
-  double ms_update_h;     /* average duration of one H half-step main kernel launch */
+  double ms_update_e;     /* average duration of one E half-step main kernel launch (net of ms_event_overhead) */
+  double ms_update_h;     /* average duration of one H half-step main kernel launch (net of ms_event_overhead) */
   int32_t launches_e;     /* launches averaged */
   int32_t launches_h;
   int32_t steps;
   int32_t fused;          /* 1: one fused launch per step (ms_update_e = that launch, ms_update_h = 0) */
+  double ms_event_overhead; /* interval of an event pair with nothing between, same stream, measured in the same
+                               call and already subtracted from ms_update_e/h (the event packets' own time) */
 } fdtd_profile;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
