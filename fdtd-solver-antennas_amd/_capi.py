@@ -17,7 +17,8 @@ HIP_LIB_NAME = "libfdtd_hip.so"
 
 ABI_SYMBOLS = [
     "fdtd_version", "fdtd_device_count", "fdtd_backend", "fdtd_create", "fdtd_destroy",
-    "fdtd_last_error", "fdtd_set_operator_raw", "fdtd_set_operator_classes", "fdtd_set_cpml",
+    "fdtd_last_error", "fdtd_set_operator_raw", "fdtd_set_operator_classes", "fdtd_build_operator",
+    "fdtd_operator_form", "fdtd_get_operator", "fdtd_set_cpml",
     "fdtd_set_mur", "fdtd_set_signal", "fdtd_add_source", "fdtd_add_probe", "fdtd_get_probe",
     "fdtd_set_dft", "fdtd_add_dft_box", "fdtd_get_dft_box", "fdtd_run", "fdtd_run_profiled",
     "fdtd_get_step", "fdtd_energy", "fdtd_comm_unique_id", "fdtd_comm_init", "fdtd_link", "fdtd_run_linked", "fdtd_half_step",
@@ -61,6 +62,9 @@ def bind(lib: C.CDLL) -> C.CDLL:
         "fdtd_last_error": (C.c_char_p, [p]),
         "fdtd_set_operator_raw": (C.c_int, [p, p, p, p, p]),
         "fdtd_set_operator_classes": (C.c_int, [p, p, C.c_int, p, p, p, p]),
+        "fdtd_build_operator": (C.c_int, [p, p, p, p, p, p, p, C.c_double, C.c_int, p, p, p, p, p, p, C.c_int]),
+        "fdtd_operator_form": (C.c_int, [p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "fdtd_get_operator": (C.c_int, [p, p, p, p, p]),
         "fdtd_set_cpml": (C.c_int, [p, p, p, p, C.c_int, C.c_int, C.c_int, p]),
         "fdtd_set_mur": (C.c_int, [p, p, p]),
         "fdtd_set_signal": (C.c_int, [p, p, C.c_int]),
@@ -192,6 +196,47 @@ class Engine:
             raise ValueError("metric/class table shape mismatch")
         self._ck(self.lib.fdtd_set_operator_classes(self._ctx, _ptr(ecls), int(cls_vv.size), _ptr(cls_vv),
                                                     _ptr(cls_m), _ptr(emet), _ptr(hmet)), "set_operator_classes")
+
+    def build_operator(self, d, eps_r, kappa, pec, eps0, overrides, emet, hmet, prefer_classes=True):
+        """Operator set-up inside the library (on the GPU for libfdtd_hip.so).  d = (dx, dy, dz) primal edge
+        lengths of the GLOBAL grid; eps_r/kappa per cell [nz-1][ny-1][nx-1]; pec [3][nz][ny][nx];
+        overrides = (edge_index int64, comp int8, vv float32, m float32) for host-fixed (lumped) edges."""
+        nx, ny, nz = self.nx, self.ny, self.nz
+        dx, dy, dz = (_arr(a, np.float64) for a in d)
+        if (dx.size, dy.size, dz.size) != (nx, ny, nz):
+            raise ValueError("cell-size tables must have nx, ny, nz entries")
+        eps_r, kappa = _arr(eps_r, np.float64), _arr(kappa, np.float64)
+        if eps_r.shape != (nz - 1, ny - 1, nx - 1) or kappa.shape != eps_r.shape:
+            raise ValueError("cell arrays must be [nz-1][ny-1][nx-1]")
+        pec = np.ascontiguousarray(pec)
+        if pec.dtype == np.bool_:
+            pec = pec.view(np.uint8)
+        pec = _arr(pec, np.uint8)
+        if pec.shape != (3, nz, ny, nx):
+            raise ValueError("pec must be [3][nz][ny][nx]")
+        oe, oc, ov, om = overrides
+        oe, oc, ov, om = _arr(oe, np.int64), _arr(oc, np.int8), _arr(ov, np.float32), _arr(om, np.float32)
+        if not (oe.size == oc.size == ov.size == om.size):
+            raise ValueError("override arrays differ in length")
+        emet, hmet = _arr(emet, np.float32), _arr(hmet, np.float32)
+        tl = nx + ny + self.nk
+        if emet.shape != (3, tl) or hmet.shape != (3, tl):
+            raise ValueError("metric table shape mismatch")
+        self._ck(self.lib.fdtd_build_operator(self._ctx, _ptr(dx), _ptr(dy), _ptr(dz), _ptr(eps_r), _ptr(kappa), _ptr(pec),
+                                              float(eps0), int(oe.size), _ptr(oe), _ptr(oc), _ptr(ov), _ptr(om),
+                                              _ptr(emet), _ptr(hmet), 1 if prefer_classes else 0), "build_operator")
+
+    def operator_form(self):
+        """('none' | 'classes' | 'classes-packed' | 'raw', number of distinct (vv, m) pairs)."""
+        form, ncls = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.fdtd_operator_form(self._ctx, C.byref(form), C.byref(ncls)), "operator_form")
+        return ("none", "classes", "classes-packed", "raw")[form.value], int(ncls.value)
+
+    def get_operator(self):
+        """(vv, vi, ii, iv) float32 [3][nk][ny][nx]: the operator that is set, expanded."""
+        out = [np.empty((3,) + self.local_shape, np.float32) for _ in range(4)]
+        self._ck(self.lib.fdtd_get_operator(self._ctx, *[_ptr(a) for a in out]), "get_operator")
+        return tuple(out)
 
     # -- boundaries ---------------------------------------------------------------------------
     def set_cpml(self, slot_x, slot_y, slot_z, nsx, nsy, nsz, coef):

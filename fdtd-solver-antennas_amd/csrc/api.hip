@@ -81,6 +81,34 @@ static hipError_t build_source_lists(const fdtd_ctx* c, int tys, int nstrips, in
   return err;
 }
 
+// metric tables of the class operator: per (E|H, comp): x (padded to P, zeros), y, z — each segment 4-float aligned
+int upload_metric_tables(fdtd_ctx* c, const float* emet, const float* hmet) {
+  const int nx = c->d.nx, ny = c->d.ny, nk = c->d.nk, P = c->P;
+  auto al4 = [](int v) { return (v + 3) / 4 * 4; };
+  // +4 floats of zero slack per table: the fused kernel reads the entries of cell i0+4, row j+1, plane k+1
+  const int sx_ = P + 4, sy_ = al4(ny) + 4, sz_ = al4(nk) + 4;
+  const int seg = sx_ + sy_ + sz_;
+  std::vector<float> host((size_t)6 * seg, 0.f);
+  const int tl = nx + ny + nk;
+  for (int eh = 0; eh < 2; ++eh)
+    for (int comp = 0; comp < 3; ++comp) {
+      const float* src = (eh ? hmet : emet) + (size_t)comp * tl;
+      float* dst = host.data() + (size_t)(eh * 3 + comp) * seg;
+      memcpy(dst, src, nx * sizeof(float));
+      memcpy(dst + sx_, src + nx, ny * sizeof(float));
+      memcpy(dst + sx_ + sy_, src + nx + ny, nk * sizeof(float));
+    }
+  if (!c->met) HIPCK(c, hipMalloc(&c->met, host.size() * sizeof(float)));
+  HIPCK(c, hipMemcpy(c->met, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  for (int comp = 0; comp < 3; ++comp) {
+    const float* e = c->met + (size_t)comp * seg;
+    const float* h = c->met + (size_t)(3 + comp) * seg;
+    c->p.emet[comp][0] = e; c->p.emet[comp][1] = e + sx_; c->p.emet[comp][2] = e + sx_ + sy_;
+    c->p.hmet[comp][0] = h; c->p.hmet[comp][1] = h + sx_; c->p.hmet[comp][2] = h + sx_ + sy_;
+  }
+  return FDTD_OK;
+}
+
 extern "C" {
 
 int fdtd_version(void) { return FDTD_ABI_VERSION; }
@@ -212,7 +240,7 @@ int fdtd_set_operator_raw(fdtd_ctx* c, const float* vv, const float* vi, const f
     HIPCK(c, upload_rows(*dst[n], c->P, src[n], c->d.nx, rows));
   }
   c->p.vv = c->vv; c->p.vi = c->vi; c->p.ii = c->ii; c->p.iv = c->iv;
-  c->have_op = true; c->raw_op = true;
+  c->have_op = true; c->raw_op = true; c->op_nclasses = 0;
   return FDTD_OK;
 }
 
@@ -269,31 +297,10 @@ int fdtd_set_operator_classes(fdtd_ctx* c, const uint8_t* ecls, int ncls, const 
       c->p.lut_n = ncls;
     }
   }
-  // metric tables: per (E|H, comp): x (padded to P, zeros), y, z — each segment 4-float aligned
-  auto al4 = [](int v) { return (v + 3) / 4 * 4; };
-  // +4 floats of zero slack per table: the fused kernel reads the entries of cell i0+4, row j+1, plane k+1
-  const int sx_ = P + 4, sy_ = al4(ny) + 4, sz_ = al4(nk) + 4;
-  const int seg = sx_ + sy_ + sz_;
-  std::vector<float> host((size_t)6 * seg, 0.f);
-  const int tl = nx + ny + nk;
-  for (int eh = 0; eh < 2; ++eh)
-    for (int comp = 0; comp < 3; ++comp) {
-      const float* src = (eh ? hmet : emet) + (size_t)comp * tl;
-      float* dst = host.data() + (size_t)(eh * 3 + comp) * seg;
-      memcpy(dst, src, nx * sizeof(float));
-      memcpy(dst + sx_, src + nx, ny * sizeof(float));
-      memcpy(dst + sx_ + sy_, src + nx + ny, nk * sizeof(float));
-    }
-  if (!c->met) HIPCK(c, hipMalloc(&c->met, host.size() * sizeof(float)));
-  HIPCK(c, hipMemcpy(c->met, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
-  for (int comp = 0; comp < 3; ++comp) {
-    const float* e = c->met + (size_t)comp * seg;
-    const float* h = c->met + (size_t)(3 + comp) * seg;
-    c->p.emet[comp][0] = e; c->p.emet[comp][1] = e + sx_; c->p.emet[comp][2] = e + sx_ + sy_;
-    c->p.hmet[comp][0] = h; c->p.hmet[comp][1] = h + sx_; c->p.hmet[comp][2] = h + sx_ + sy_;
-  }
+  { int r = upload_metric_tables(c, emet, hmet); if (r) return r; }
   c->p.ecls = c->ecls; c->p.lut = c->lut;
   c->have_op = true; c->raw_op = false;
+  c->op_nclasses = ncls;
   return FDTD_OK;
 }
 

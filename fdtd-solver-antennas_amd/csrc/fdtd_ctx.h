@@ -15,9 +15,7 @@
 #define FDTD_MAX_PROBES 64
 #define FDTD_MAX_BOXES 64
 #ifndef FDTD_BLOCK
-#ifndef FDTD_BLOCK
 #define FDTD_BLOCK 256
-#endif
 #endif
 
 struct DevParams {
@@ -85,6 +83,7 @@ struct fdtd_ctx {
   float2* lut = nullptr;
   float* met = nullptr;          // packed metric tables
   bool have_op = false, raw_op = false, packed_op = false;
+  int op_nclasses = 0;           // distinct (vv, m) pairs of the class operator (0: raw)
   int2* src_rng = nullptr; int* src_ids = nullptr;
   // cpml
   bool have_cpml = false;
@@ -129,6 +128,7 @@ int fdtd_fail(fdtd_ctx* c, int code, const char* fmt, ...);
 // kernels.hip
 // `fused`: sources injected inside update_E; `probe_block`: one extra block samples the probes
 // (update_E: I-probes of step-1, update_H: V-probes of step) so a step is exactly two launches.
+int upload_metric_tables(fdtd_ctx* c, const float* emet, const float* hmet);
 void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool fused, bool probe_block, hipStream_t s);
 void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s);
 void launch_mur(fdtd_ctx* c, int mode, hipStream_t s);

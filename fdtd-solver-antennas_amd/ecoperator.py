@@ -15,6 +15,11 @@ Two output forms:
   * raw     — the four coefficient arrays as float32 (12 B/cell-step of extra HBM traffic ×4);
   * classes — one uint8 class per edge + separable 1-D metric tables (3 B/cell-step), exactly
               the factorisation documented at fdtd_set_operator_classes().
+
+This numpy formulation is the SPEC of the operator.  The product path does not run it: Simulation.build hands
+materials + mesh to fdtd_build_operator (HIP kernels in csrc/opbuild.hip; plain C in the oracle), which must
+reproduce these arrays bit for bit (tests/test_operator_build_*.py); only metric_lists / lumped_overrides (1-D
+tables, a handful of edges) are evaluated on the host.
 """
 from __future__ import annotations
 
@@ -89,12 +94,7 @@ class ECOperator:
 
     def metric_tables(self, k0: int = 0, nk: Optional[int] = None):
         """emet, hmet packed as [3][nx + ny + nk] float32 (z part local to the slab)."""
-        nx, ny, nz = self.grid.shape
-        nk = nz - k0 if nk is None else nk
-        sl = slice(k0, k0 + nk)
-        e = np.concatenate([np.concatenate([t[0], t[1], t[2][sl]]) for t in self.emet]).astype(np.float32)
-        h = np.concatenate([np.concatenate([t[0], t[1], t[2][sl]]) for t in self.hmet]).astype(np.float32)
-        return e.reshape(3, nx + ny + nk), h.reshape(3, nx + ny + nk)
+        return pack_metric_tables(self.emet, self.hmet, self.grid, k0, nk)
 
 
 def _edge_average(cellval: np.ndarray, grid: RectGrid, comp: int) -> np.ndarray:
@@ -149,7 +149,6 @@ def build_operator(grid: RectGrid, eps_r: np.ndarray, kappa: np.ndarray, pec: np
     n_axis = (nx, ny, nz)
     vv = np.empty((3, nz, ny, nx), np.float32)
     m = np.empty((3, nz, ny, nx), np.float32)
-    emet, hmet = [], []
     for c in range(3):
         eps_e = _edge_average(eps_r, grid, c) * EPS0
         kap_e = _edge_average(kappa, grid, c)
@@ -174,7 +173,20 @@ def build_operator(grid: RectGrid, eps_r: np.ndarray, kappa: np.ndarray, pec: np
         m_c[dead] = 0.0
         vv[c] = vv_c
         m[c] = m_c
-        # separable metric: vi = m * l[c] / (dd[a1] * dd[a2]);  iv = (dt/mu0) * dd[c] / (d[a1] * d[a2])
+    emet, hmet = metric_lists(grid, dt)
+    op = ECOperator(grid=grid, dt=dt, vv=vv, m=m, emet=emet, hmet=hmet)
+    # lumped conductances: (vv, m) of those edges with G_total = kappa*A~/l + G
+    edge, comp, o_vv, o_m = lumped_overrides(grid, eps_r, kappa, pec, dt, lumped)
+    op.vv.reshape(3, -1)[comp, edge] = o_vv
+    op.m.reshape(3, -1)[comp, edge] = o_m
+    return op
+
+
+def metric_lists(grid: RectGrid, dt: float):
+    """Separable metric of the EC operator: vi = m * l[c] / (dd[a1] * dd[a2]);  iv = (dt/mu0) * dd[c] / (d[a1] * d[a2]).
+    emet[c][axis], hmet[c][axis] -> 1-D float32 tables over the whole grid."""
+    emet, hmet = [], []
+    for c in range(3):
         et, ht = [None] * 3, [None] * 3
         for a in range(3):
             if a == c:
@@ -189,8 +201,25 @@ def build_operator(grid: RectGrid, eps_r: np.ndarray, kappa: np.ndarray, pec: np
                 ht[a] = inv.astype(np.float32)
         emet.append(et)
         hmet.append(ht)
-    op = ECOperator(grid=grid, dt=dt, vv=vv, m=m, emet=emet, hmet=hmet)
-    # lumped conductances: recompute (vv, m) of those edges with G_total = kappa*A~/l + G
+    return emet, hmet
+
+
+def pack_metric_tables(emet, hmet, grid: RectGrid, k0: int = 0, nk: Optional[int] = None):
+    """emet, hmet packed as [3][nx + ny + nk] float32 (z part local to the slab) — the C ABI's table argument."""
+    nx, ny, nz = grid.shape
+    nk = nz - k0 if nk is None else nk
+    sl = slice(k0, k0 + nk)
+    e = np.concatenate([np.concatenate([t[0], t[1], t[2][sl]]) for t in emet]).astype(np.float32)
+    h = np.concatenate([np.concatenate([t[0], t[1], t[2][sl]]) for t in hmet]).astype(np.float32)
+    return e.reshape(3, nx + ny + nk), h.reshape(3, nx + ny + nk)
+
+
+def lumped_overrides(grid: RectGrid, eps_r: np.ndarray, kappa: np.ndarray, pec: np.ndarray, dt: float,
+                     lumped: Sequence[LumpedEdge]):
+    """(global edge index int64, comp int8, vv float32, m float32) of the edges that carry a lumped conductance —
+    the few coefficients the host fixes itself when the operator is built on the device (fdtd_build_operator)."""
+    nx, ny, nz = grid.shape
+    edge, comp, o_vv, o_m = [], [], [], []
     for le in lumped:
         c, i, j, k = le.comp, le.i, le.j, le.k
         if pec[c, k, j, i]:
@@ -199,15 +228,16 @@ def build_operator(grid: RectGrid, eps_r: np.ndarray, kappa: np.ndarray, pec: np
         a1, a2 = (c + 1) % 3, (c + 2) % 3
         l = grid.d[c][pos[c]]
         A = grid.dd[a1][pos[a1]] * grid.dd[a2][pos[a2]]
-        # recover eps/kappa of the edge from the unlumped coefficients
         eps_e = _edge_scalar(eps_r, grid, c, pos) * EPS0
         kap_e = _edge_scalar(kappa, grid, c, pos)
         C = eps_e * A / l
         G = kap_e * A / l + le.G
         x = 0.5 * dt * G / C
-        op.vv[c, k, j, i] = np.float32((1.0 - x) / (1.0 + x))
-        op.m[c, k, j, i] = np.float32(dt / (eps_e * (1.0 + x)))
-    return op
+        edge.append((k * ny + j) * nx + i)
+        comp.append(c)
+        o_vv.append(np.float32((1.0 - x) / (1.0 + x)))
+        o_m.append(np.float32(dt / (eps_e * (1.0 + x))))
+    return (np.asarray(edge, np.int64), np.asarray(comp, np.int8), np.asarray(o_vv, np.float32), np.asarray(o_m, np.float32))
 
 
 def _edge_scalar(cellval, grid, comp, pos):

@@ -14,7 +14,7 @@ import numpy as np
 from .constants import C0, EPS0, MU0
 from .grid import RectGrid
 from .scene import VoxelScene
-from .ecoperator import build_operator, ECOperator
+from .ecoperator import build_operator, ECOperator, metric_lists, pack_metric_tables, lumped_overrides
 from .cpml import CPMLSpec, build_cpml
 from .excitation import gauss_pulse, dft_twiddles
 from .nf2ff import NF2FFBox
@@ -74,14 +74,18 @@ class Simulation:
     def __init__(self, grid: RectGrid, vox: VoxelScene, *, f0: float, fc: float, boundary="CPML",
                  cpml_cells: Optional[int] = None, nr_ts: int = 30000, end_criteria: float = 1e-4,
                  dt: Optional[float] = None, nf2ff_freqs: Optional[Sequence[float]] = None,
-                 nf2ff_inset: Optional[int] = None, dft_oversample: float = 4.0, use_classes: bool = True):
+                 nf2ff_inset: Optional[int] = None, dft_oversample: float = 4.0, use_classes: bool = True,
+                 device_operator: bool = True):
         self.grid, self.vox = grid, vox
         self.f0, self.fc = float(f0), float(fc)
         self.bc = BoundarySpec.parse(boundary, cpml_cells)
         self.nr_ts, self.end_criteria = int(nr_ts), float(end_criteria)
         self.dt = grid.courant_dt() if dt is None else float(dt)
         self.use_classes = use_classes
-        self.op: ECOperator = build_operator(grid, vox.eps_r, vox.kappa, vox.pec, self.dt, vox.lumped)
+        # True: the engine builds the operator itself from materials + mesh (fdtd_build_operator: on the GPU for
+        # libfdtd_hip.so); False: numpy build on the host (ecoperator.build_operator, the spec) + array upload
+        self.device_operator = device_operator
+        self._op: Optional[ECOperator] = None
         cells = self.bc.face_cells()
         self.cpml = None
         if any(cells):
@@ -116,6 +120,14 @@ class Simulation:
         self._port_probe_ids = []
         self._nf_ids = []
 
+    @property
+    def op(self) -> ECOperator:
+        """The operator in its host (numpy) formulation — built on first use; the default product path never asks."""
+        if self._op is None:
+            v = self.vox
+            self._op = build_operator(self.grid, v.eps_r, v.kappa, v.pec, self.dt, v.lumped)
+        return self._op
+
     # ---------------------------------------------------------------------------------------------
     def build(self, lib, *, rank: int = 0, world: int = 1, device: int = 0, flags: int = 0) -> Engine:
         g = self.grid
@@ -125,14 +137,22 @@ class Simulation:
             raise ValueError(f"slab of rank {rank} has {nk} planes; need >= 2")
         e = Engine(lib, nx, ny, nz, self.dt, k0=k0, nk=nk, rank=rank, world=world, device=device,
                    max_steps=self.nr_ts, flags=flags)
-        cls = self.op.classes(k0, nk) if self.use_classes else None
-        if cls is not None:
-            emet, hmet = self.op.metric_tables(k0, nk)
-            e.set_operator_classes(cls[0], cls[1], cls[2], emet, hmet)
-            self.operator_form = "classes"
+        if self.device_operator:
+            v = self.vox
+            emet, hmet = pack_metric_tables(*metric_lists(g, self.dt), g, k0, nk)
+            e.build_operator(g.d, v.eps_r, v.kappa, v.pec, EPS0,
+                             lumped_overrides(g, v.eps_r, v.kappa, v.pec, self.dt, v.lumped), emet, hmet,
+                             prefer_classes=self.use_classes)
+            self.operator_form = "raw" if e.operator_form()[0] == "raw" else "classes"
         else:
-            e.set_operator_raw(*self.op.raw(k0, nk))
-            self.operator_form = "raw"
+            cls = self.op.classes(k0, nk) if self.use_classes else None
+            if cls is not None:
+                emet, hmet = self.op.metric_tables(k0, nk)
+                e.set_operator_classes(cls[0], cls[1], cls[2], emet, hmet)
+                self.operator_form = "classes"
+            else:
+                e.set_operator_raw(*self.op.raw(k0, nk))
+                self.operator_form = "raw"
         if self.cpml is not None:
             e.set_cpml(*self.cpml.for_slab(k0, nk))
         if self.mur_enable.any():

@@ -125,6 +125,28 @@ int fdtd_set_operator_classes(fdtd_ctx* ctx, const uint8_t* ecls, int ncls,
                               const float* cls_vv, const float* cls_m,
                               const float* emet, const float* hmet);
 
+/* Operator set-up ON THE DEVICE (the operator-build phase the reference triggers inside FDTD.Run,
+ * solver_fdtd_openems_fixed.py:280): per-cell materials, PEC edge flags and primal cell sizes in; the
+ * class-compressed operator out (raw if the slab has more than 256 distinct (vv, m) pairs or prefer_classes == 0).
+ * Bit for bit what the host formulation gives: for a live edge of component c (a1, a2 the other two axes),
+ *   eps_e = EPS0 * sum(eps_r*w) / sum(w),  kap_e = sum(kappa*w) / sum(w)  over the 4 cells around the edge,
+ *   w = d[a1]*d[a2] of the cell, summed with the a1 offset outer (-1, 0) and the a2 offset inner (-1, 0), float64;
+ *   x = ((0.5*dt)*kap_e)/eps_e;  vv = (float)((1-x)/(1+x));  m = (float)(dt/(eps_e*(1+x)));
+ * dead edges (pec != 0, last index along c, first/last index along a1 or a2) get vv = m = 0; then the overrides.
+ *   dx,dy,dz   primal edge lengths of the GLOBAL grid (nx, ny, nz entries)
+ *   eps_r,kappa  per cell of the GLOBAL grid [nz-1][ny-1][nx-1];  pec  [3][nz][ny][nx] bytes of the GLOBAL grid
+ *   over_*     edges whose (vv, m) the host fixes itself (lumped elements): global edge index (k*ny + j)*nx + i
+ *   emet,hmet  as in fdtd_set_operator_classes */
+int fdtd_build_operator(fdtd_ctx* ctx, const double* dx, const double* dy, const double* dz,
+                        const double* eps_r, const double* kappa, const uint8_t* pec, double eps0,
+                        int n_over, const int64_t* over_edge, const int8_t* over_comp,
+                        const float* over_vv, const float* over_m,
+                        const float* emet, const float* hmet, int prefer_classes);
+/* form: 0 none, 1 classes (one byte per edge), 2 classes packed (one byte per cell), 3 raw. */
+int fdtd_operator_form(fdtd_ctx* ctx, int* form, int* nclasses);
+/* The operator that is set, expanded to the four raw arrays, each [3][nk][ny][nx] (parity / debugging). */
+int fdtd_get_operator(fdtd_ctx* ctx, float* vv, float* vi, float* ii, float* iv);
+
 /* ---- absorbing boundaries --------------------------------------------------------------- */
 /* CPML.  slot_a[idx] >= 0 gives the psi storage slot of index idx along axis a (-1: no psi).
  * coef: [3 axes][2 (0: E-located = node, 1: H-located = half node)][3 (b, c, 1/kappa)][n_a]
