@@ -229,6 +229,7 @@ void fdtd_destroy(fdtd_ctx* c) {
 
 int fdtd_set_operator_raw(fdtd_ctx* c, const float* vv, const float* vi, const float* ii, const float* iv) {
   if (!c || !vv || !vi || !ii || !iv) return fdtd_fail(c, FDTD_E_ARG, "null operator array");
+  if (3 * c->nloc >= ((size_t)1 << 31)) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "raw operator: slab exceeds 2^31 / 3 elements per component (use more z-slabs)");
   HIPCK(c, hipSetDevice(c->d.device));
   const size_t bytes = 3 * c->nloc * sizeof(float);
   const float* src[4] = {vv, vi, ii, iv};
@@ -275,6 +276,8 @@ int fdtd_set_operator_classes(fdtd_ctx* c, const uint8_t* ecls, int ncls, const 
       packed[q] = (uint8_t)sidx;
     }
     c->packed_op = ok;
+    if (!ok && 3 * c->nloc >= ((size_t)1 << 31))
+      return fdtd_fail(c, FDTD_E_UNSUPPORTED, "per-edge class operator: slab exceeds 2^31 / 3 elements per component (use more z-slabs)");
     if (ok) {
       HIPCK(c, upload_rows(c->ecls, P, packed.data(), nx, (size_t)nk * ny));
       std::vector<float2> lut3(768, make_float2(0.f, 0.f));

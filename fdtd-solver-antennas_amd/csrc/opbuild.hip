@@ -319,6 +319,8 @@ int fdtd_build_operator(fdtd_ctx* c, const double* dx, const double* dy, const d
     std::vector<unsigned long long> triples;
     bool packed = false;
     { int r = collect_sorted(c, 1, nullptr, cls.p, ncell, ncell, triples, packed); if (r) return r; }
+    if (!packed && 3 * c->nloc >= ((size_t)1 << 31))
+      return fdtd_fail(c, FDTD_E_UNSUPPORTED, "per-edge class operator: slab exceeds 2^31 / 3 elements per component (use more z-slabs)");
     const size_t n_alloc = 3 * c->nloc + (size_t)c->plane + 64;   // same slack as fdtd_set_operator_classes
     if (!c->ecls) HIPCK(c, hipMalloc(&c->ecls, n_alloc));
     HIPCK(c, hipMemsetAsync(c->ecls, 0, n_alloc, c->stream));
@@ -350,6 +352,8 @@ int fdtd_build_operator(fdtd_ctx* c, const double* dx, const double* dy, const d
     c->have_op = true; c->raw_op = false;
     c->op_nclasses = (int)keys.size();
   } else {
+    if (3 * c->nloc >= ((size_t)1 << 31))
+      return fdtd_fail(c, FDTD_E_UNSUPPORTED, "raw operator: slab exceeds 2^31 / 3 elements per component (use more z-slabs)");
     const size_t bytes = 3 * c->nloc * sizeof(float);
     float** dst[4] = {&c->vv, &c->vi, &c->ii, &c->iv};
     for (int n = 0; n < 4; ++n) {
