@@ -45,24 +45,40 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, cons
   int strip, kk, pb;
   decode_block(p.nbs, nkr, extra, strip, kk, pb);
   const int k = k_begin + kk;
-  if (COEF != 0)
-    for (int q = threadIdx.x; q < p.lut_n; q += FDTD_BLOCK) s_lut[q] = p.lut[q];
+  // coefficient table -> registers now, -> LDS after the field loads have been issued (loads return in order, so
+  // waiting for these few entries leaves the field loads in flight)
+  constexpr int NLUT = COEF == 2 ? 768 : (COEF == 1 ? 256 : 0);
+  constexpr int NLR = (NLUT + FDTD_BLOCK - 1) / FDTD_BLOCK;
+  float2 lut_r[NLR > 0 ? NLR : 1];
+#pragma unroll
+  for (int q = 0; q < NLR; ++q) {
+    const int e = q * FDTD_BLOCK + (int)threadIdx.x;
+    lut_r[q] = e < p.lut_n ? p.lut[e] : make_float2(0.f, 0.f);
+  }
+  // the field loads are issued BEFORE the barrier that publishes the LDS tables, so that their latency overlaps
+  // the table staging instead of following it (out-of-range threads of the last block read their block's first
+  // group, in range by construction, and leave after the barrier)
+  int j = 0, i0 = 0;
+  const bool valid = decode_thread(p, strip, pb, j, i0);
+  const int off = k * p.plane + (valid ? j * p.P + i0 : 0);
+  const float4 ix = ld4(p.I[0] + off), iy = ld4(p.I[1] + off), iz = ld4(p.I[2] + off);
+  const float4 iz_jm = ld4(p.I[2] + off - p.P), ix_jm = ld4(p.I[0] + off - p.P);
+  const float4 iy_km = ld4(p.I[1] + off - p.plane), ix_km = ld4(p.I[0] + off - p.plane);
+  const float iz_im = p.I[2][off - 1], iy_im = p.I[1][off - 1];
+  float4 vx = ld4(p.V[0] + off), vy = ld4(p.V[1] + off), vz = ld4(p.V[2] + off);
   // soft sources inside this strip-plane (block-uniform range; almost always empty)
   int2 srng = make_int2(0, 0);
   if (FUSE && p.nsrc > 0) {
     srng = p.src_rng[k * p.nstrips + strip];
     stage_sources(p, p.src_ids, srng.x, min(srng.y - srng.x, FDTD_BLOCK), step, s_src);
   }
+#pragma unroll
+  for (int q = 0; q < NLR; ++q) {
+    const int e = q * FDTD_BLOCK + (int)threadIdx.x;
+    if (e < p.lut_n) s_lut[e] = lut_r[q];
+  }
   if (COEF != 0 || (FUSE && p.nsrc > 0)) __syncthreads();
-  int j, i0;
-  if (!decode_thread(p, strip, pb, j, i0)) return;
-  const int off = k * p.plane + j * p.P + i0;
-
-  const float4 ix = ld4(p.I[0] + off), iy = ld4(p.I[1] + off), iz = ld4(p.I[2] + off);
-  const float4 iz_jm = ld4(p.I[2] + off - p.P), ix_jm = ld4(p.I[0] + off - p.P);
-  const float4 iy_km = ld4(p.I[1] + off - p.plane), ix_km = ld4(p.I[0] + off - p.plane);
-  const float iz_im = p.I[2][off - 1], iy_im = p.I[1][off - 1];
-  float4 vx = ld4(p.V[0] + off), vy = ld4(p.V[1] + off), vz = ld4(p.V[2] + off);
+  if (!valid) return;
 
   // component x: d1 along y (of Iz), d2 along z (of Iy); y: d1 along z (Ix), d2 along x (Iz);
   // z: d1 along x (Iy), d2 along y (Ix)
