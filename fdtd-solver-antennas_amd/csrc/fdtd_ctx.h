@@ -17,6 +17,13 @@
 #ifndef FDTD_BLOCK
 #define FDTD_BLOCK 256
 #endif
+// minimum resident blocks per CU the update kernels are compiled for (register budget = occupancy target)
+#ifndef FDTD_E_MINBLOCKS
+#define FDTD_E_MINBLOCKS 7
+#endif
+#ifndef FDTD_H_MINBLOCKS
+#define FDTD_H_MINBLOCKS 7
+#endif
 
 struct DevParams {
   int nx, ny, nk, P, P4;
@@ -74,6 +81,7 @@ struct fdtd_ctx {
   int2* src_rng2 = nullptr; int* src_ids2 = nullptr;
   int2* src_rng3 = nullptr; int* src_ids3 = nullptr;
   int2* src_rng4 = nullptr; int* src_ids4 = nullptr;
+  int occ_e = 0, occ_h = 0;      // cap on resident blocks per CU of update_E / update_H (0: none); $FDTD_OCC_E / $FDTD_OCC_H
   int march_kc = 0;              // z-marching kernel: planes per chunk ($FDTD_MARCH_KC, default 10)
   bool fused_ready = false;
   int tile_shape = 0x88;         // LDS-tile kernel: (TY << 4) | TZ threads; $FDTD_TILE_SHAPE = 88 | 48 | 84 | 44

@@ -6,6 +6,14 @@ namespace {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+// Scalar base + 32-bit unsigned BYTE offset: selects the `global_load ... v_off, s[base]` addressing form, i.e. one
+// VGPR per address instead of a 64-bit pair (the update kernels are occupancy-sensitive).  e = element offset >= 0.
+__device__ __forceinline__ float4 ldo4(const float* base, const unsigned e) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (e << 2));
+}
+__device__ __forceinline__ float ldo1(const float* base, const unsigned e) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (e << 2));
+}
 // streamed outputs: non-temporal once the working set exceeds the 256 MiB Infinity Cache (measured on
 // MI355X: +3-4 % at 400x400x80, -15 % at 300x300x60 where the fields live in the cache)
 typedef float v4f_nt __attribute__((ext_vector_type(4)));
@@ -16,6 +24,9 @@ __device__ __forceinline__ void st4s(const int nt, float* p, const float4& v) {
   } else {
     *reinterpret_cast<float4*>(p) = v;
   }
+}
+__device__ __forceinline__ void sto4s(const int nt, float* base, const unsigned e, const float4& v) {
+  st4s(nt, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (e << 2)), v);
 }
 __device__ __forceinline__ float4 sub4(const float4& a, const float4& b) {
   return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
@@ -98,7 +109,8 @@ __device__ __forceinline__ int pml_slot(const DevParams& p, int a, int q) {
 }
 
 // psi <- b*psi + c*d ; d <- d/kappa + psi   for the four cells of a thread (row-uniform coefficients)
-__device__ __forceinline__ void cpml_row4(float4& d, float* psi, float b, float c, float ik) {
+__device__ __forceinline__ void cpml_row4(float4& d, float* base, const unsigned o, float b, float c, float ik) {
+  float* psi = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (o << 2));   // scalar base + 32-bit offset
   float4 ps = ld4(psi);
   ps.x = __builtin_fmaf(b, ps.x, c * d.x);
   ps.y = __builtin_fmaf(b, ps.y, c * d.y);

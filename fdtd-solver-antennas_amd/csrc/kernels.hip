@@ -33,7 +33,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // COEF: 0 raw arrays, 1 class byte per edge, 2 one packed class byte per cell
 template <int COEF, bool PML, bool FUSE>
-__global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, const int k_begin, const int nkr,
+__global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const int nkr,
                                                          const long long step, const int extra) {
   __shared__ float2 s_lut[COEF == 2 ? 768 : (COEF == 1 ? 256 : 1)];
   __shared__ double s_red[FUSE ? FDTD_BLOCK : 1];
@@ -61,11 +61,14 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, cons
   int j = 0, i0 = 0;
   const bool valid = decode_thread(p, strip, pb, j, i0);
   const int off = k * p.plane + (valid ? j * p.P + i0 : 0);
-  const float4 ix = ld4(p.I[0] + off), iy = ld4(p.I[1] + off), iz = ld4(p.I[2] + off);
-  const float4 iz_jm = ld4(p.I[2] + off - p.P), ix_jm = ld4(p.I[0] + off - p.P);
-  const float4 iy_km = ld4(p.I[1] + off - p.plane), ix_km = ld4(p.I[0] + off - p.plane);
-  const float iz_im = p.I[2][off - 1], iy_im = p.I[1][off - 1];
-  float4 vx = ld4(p.V[0] + off), vy = ld4(p.V[1] + off), vz = ld4(p.V[2] + off);
+  // scalar bases one plane below plane 0 (the ghost plane), so that every offset — also k-1, j-1, i-1 — is unsigned
+  const unsigned uo = (unsigned)(off + p.plane);
+  const float *I0 = p.I[0] - p.plane, *I1 = p.I[1] - p.plane, *I2 = p.I[2] - p.plane;
+  const float4 ix = ldo4(I0, uo), iy = ldo4(I1, uo), iz = ldo4(I2, uo);
+  const float4 iz_jm = ldo4(I2, uo - p.P), ix_jm = ldo4(I0, uo - p.P);
+  const float4 iy_km = ldo4(I1, uo - p.plane), ix_km = ldo4(I0, uo - p.plane);
+  const float iz_im = ldo1(I2, uo - 1), iy_im = ldo1(I1, uo - 1);
+  float4 vx = ldo4(p.V[0], (unsigned)off), vy = ldo4(p.V[1], (unsigned)off), vz = ldo4(p.V[2], (unsigned)off);
   // soft sources inside this strip-plane (block-uniform range; almost always empty)
   int2 srng = make_int2(0, 0);
   if (FUSE && p.nsrc > 0) {
@@ -93,15 +96,15 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, cons
     if (sy >= 0) {
       const float b = p.cp[1][0][0][j], c = p.cp[1][0][1][j], ik = p.cp[1][0][2][j];
       const int o = (k * p.nslot[1] + sy) * p.P + i0;
-      cpml_row4(dx1, p.psiE[0][0] + o, b, c, ik);
-      cpml_row4(dz2, p.psiE[2][1] + o, b, c, ik);
+      cpml_row4(dx1, p.psiE[0][0], (unsigned)o, b, c, ik);
+      cpml_row4(dz2, p.psiE[2][1], (unsigned)o, b, c, ik);
     }
     const int sz = pml_slot(p, 2, k);
     if (sz >= 0) {
       const float b = p.cp[2][0][0][k], c = p.cp[2][0][1][k], ik = p.cp[2][0][2][k];
       const int o = (sz * p.ny + j) * p.P + i0;
-      cpml_row4(dx2, p.psiE[0][1] + o, b, c, ik);
-      cpml_row4(dy1, p.psiE[1][0] + o, b, c, ik);
+      cpml_row4(dx2, p.psiE[0][1], (unsigned)o, b, c, ik);
+      cpml_row4(dy1, p.psiE[1][0], (unsigned)o, b, c, ik);
     }
     if (i0 < p.pml_lo[0] || i0 + 3 >= p.pml_hi[0])
       cpml_x4(p, 0, i0, (k * p.ny + j) * p.nslot[0], dy2, p.psiE[1][1], dz1, p.psiE[2][0]);
@@ -168,16 +171,16 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_E(const DevParams p, cons
       }
     }
   }
-  st4s(p.nt, p.V[0] + off, vx);
-  st4s(p.nt, p.V[1] + off, vy);
-  st4s(p.nt, p.V[2] + off, vz);
+  sto4s(p.nt, p.V[0], (unsigned)off, vx);
+  sto4s(p.nt, p.V[1], (unsigned)off, vy);
+  sto4s(p.nt, p.V[2], (unsigned)off, vz);
 }
 
 // ------------------------------------------------------------------------------------------------
 // K2: H half-step
 // ------------------------------------------------------------------------------------------------
 template <bool RAW, bool PML>
-__global__ __launch_bounds__(FDTD_BLOCK) void k_update_H(const DevParams p, const int k_begin, const int nkr,
+__global__ __launch_bounds__(FDTD_BLOCK, FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const int nkr,
                                                          const long long step, const int extra) {
   __shared__ double s_red[FDTD_BLOCK];
   if (extra && blockIdx.x == gridDim.x - 1) {   // probe block: V-probes of this step (V is final, H not read)
@@ -190,11 +193,12 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_H(const DevParams p, cons
   if (!decode_thread(p, strip, pb, j, i0)) return;
   const int off = k * p.plane + j * p.P + i0;
 
-  const float4 vx = ld4(p.V[0] + off), vy = ld4(p.V[1] + off), vz = ld4(p.V[2] + off);
-  const float4 vz_jp = ld4(p.V[2] + off + p.P), vx_jp = ld4(p.V[0] + off + p.P);
-  const float4 vy_kp = ld4(p.V[1] + off + p.plane), vx_kp = ld4(p.V[0] + off + p.plane);
-  const float vz_ip = p.V[2][off + 4], vy_ip = p.V[1][off + 4];
-  float4 ix = ld4(p.I[0] + off), iy = ld4(p.I[1] + off), iz = ld4(p.I[2] + off);
+  const unsigned uo = (unsigned)off;     // H reads planes k, k+1 only: offsets from plane 0 are never negative
+  const float4 vx = ldo4(p.V[0], uo), vy = ldo4(p.V[1], uo), vz = ldo4(p.V[2], uo);
+  const float4 vz_jp = ldo4(p.V[2], uo + p.P), vx_jp = ldo4(p.V[0], uo + p.P);
+  const float4 vy_kp = ldo4(p.V[1], uo + p.plane), vx_kp = ldo4(p.V[0], uo + p.plane);
+  const float vz_ip = ldo1(p.V[2], uo + 4), vy_ip = ldo1(p.V[1], uo + 4);
+  float4 ix = ldo4(p.I[0], uo), iy = ldo4(p.I[1], uo), iz = ldo4(p.I[2], uo);
 
   float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);
   float4 dy1 = sub4(vx, vx_kp);
@@ -207,15 +211,15 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_H(const DevParams p, cons
     if (sy >= 0) {
       const float b = p.cp[1][1][0][j], c = p.cp[1][1][1][j], ik = p.cp[1][1][2][j];
       const int o = (k * p.nslot[1] + sy) * p.P + i0;
-      cpml_row4(dx1, p.psiH[0][0] + o, b, c, ik);
-      cpml_row4(dz2, p.psiH[2][1] + o, b, c, ik);
+      cpml_row4(dx1, p.psiH[0][0], (unsigned)o, b, c, ik);
+      cpml_row4(dz2, p.psiH[2][1], (unsigned)o, b, c, ik);
     }
     const int sz = pml_slot(p, 2, k);
     if (sz >= 0) {
       const float b = p.cp[2][1][0][k], c = p.cp[2][1][1][k], ik = p.cp[2][1][2][k];
       const int o = (sz * p.ny + j) * p.P + i0;
-      cpml_row4(dx2, p.psiH[0][1] + o, b, c, ik);
-      cpml_row4(dy1, p.psiH[1][0] + o, b, c, ik);
+      cpml_row4(dx2, p.psiH[0][1], (unsigned)o, b, c, ik);
+      cpml_row4(dy1, p.psiH[1][0], (unsigned)o, b, c, ik);
     }
     if (i0 < p.pml_lo[0] || i0 + 3 >= p.pml_hi[0])
       cpml_x4(p, 1, i0, (k * p.ny + j) * p.nslot[0], dy2, p.psiH[1][1], dz1, p.psiH[2][0]);
@@ -241,9 +245,9 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_update_H(const DevParams p, cons
     iz = make_float4(iz.x + (hx2.x * m2) * (dz1.x - dz2.x), iz.y + (hx2.y * m2) * (dz1.y - dz2.y),
                      iz.z + (hx2.z * m2) * (dz1.z - dz2.z), iz.w + (hx2.w * m2) * (dz1.w - dz2.w));
   }
-  st4s(p.nt, p.I[0] + off, ix);
-  st4s(p.nt, p.I[1] + off, iy);
-  st4s(p.nt, p.I[2] + off, iz);
+  sto4s(p.nt, p.I[0], uo, ix);
+  sto4s(p.nt, p.I[1], uo, iy);
+  sto4s(p.nt, p.I[2], uo, iz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -380,10 +384,20 @@ void choose_tiling(fdtd_ctx* c) {
   c->p.nstrips = (ny + best - 1) / best;
 }
 
+// Occupancy cap without recompiling: dynamic LDS padding so that at most `cap` blocks fit the CU's 160 KiB
+// (0 = no cap).  More resident waves are not always faster here: HBM-resident grids lose L2 reuse of the k-1 / j-1
+// neighbour rows when too many strips are in flight.
+static unsigned lds_pad(int cap, unsigned static_bytes) {
+  if (cap <= 0) return 0;
+  const unsigned total = (163840u / (unsigned)cap) & ~1023u;
+  return total > static_bytes ? total - static_bytes : 0;
+}
+
 template <int COEF, bool PML>
 static void launch_E2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long step, bool fused, int extra, hipStream_t s) {
-  if (fused) hipLaunchKernelGGL((k_update_E<COEF, PML, true>), grid, dim3(FDTD_BLOCK), 0, s, c->p, k_begin, nkr, step, extra);
-  else hipLaunchKernelGGL((k_update_E<COEF, PML, false>), grid, dim3(FDTD_BLOCK), 0, s, c->p, k_begin, nkr, step, 0);
+  const unsigned pad = lds_pad(c->occ_e, 11264u);
+  if (fused) hipLaunchKernelGGL((k_update_E<COEF, PML, true>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, nkr, step, extra);
+  else hipLaunchKernelGGL((k_update_E<COEF, PML, false>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, nkr, step, 0);
 }
 
 void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool fused, bool probe_block, hipStream_t s) {
@@ -408,12 +422,13 @@ void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool p
   if (nkr <= 0) return;
   const int extra = probe_block ? 1 : 0;
   const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs + extra)), block(FDTD_BLOCK);
+  const unsigned pad = lds_pad(c->occ_h, 2560u);
   if (c->raw_op) {
-    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<true, true>), grid, block, 0, s, c->p, k_begin, nkr, step, extra);
-    else hipLaunchKernelGGL((k_update_H<true, false>), grid, block, 0, s, c->p, k_begin, nkr, step, extra);
+    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<true, true>), grid, block, pad, s, c->p, k_begin, nkr, step, extra);
+    else hipLaunchKernelGGL((k_update_H<true, false>), grid, block, pad, s, c->p, k_begin, nkr, step, extra);
   } else {
-    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<false, true>), grid, block, 0, s, c->p, k_begin, nkr, step, extra);
-    else hipLaunchKernelGGL((k_update_H<false, false>), grid, block, 0, s, c->p, k_begin, nkr, step, extra);
+    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<false, true>), grid, block, pad, s, c->p, k_begin, nkr, step, extra);
+    else hipLaunchKernelGGL((k_update_H<false, false>), grid, block, pad, s, c->p, k_begin, nkr, step, extra);
   }
 }
 
