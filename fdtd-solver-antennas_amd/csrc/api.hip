@@ -135,7 +135,8 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   if (d->device < 0 || d->device >= ndev) return fdtd_fail(nullptr, FDTD_E_ARG, "device %d of %d", d->device, ndev);
   const long P = (d->nx + 3) / 4 * 4;
   const long plane = P * d->ny;
-  if (plane * (long)(d->nk + 2) >= (1L << 31)) return fdtd_fail(nullptr, FDTD_E_UNSUPPORTED, "slab exceeds 2^31 elements per component");
+  // the update kernels address every array as scalar base + 32-bit BYTE offset
+  if (plane * (long)(d->nk + 2) >= (1L << 30)) return fdtd_fail(nullptr, FDTD_E_UNSUPPORTED, "slab exceeds 2^30 elements (4 GiB) per field component: use more z-slabs (several slabs may share one GPU, fdtd_link)");
   fdtd_ctx* c = new (std::nothrow) fdtd_ctx();
   if (!c) return fdtd_fail(nullptr, FDTD_E_NOMEM, "ctx");
   c->d = *d;
