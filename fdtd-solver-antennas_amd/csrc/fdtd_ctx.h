@@ -25,6 +25,21 @@
 #define FDTD_H_MINBLOCKS 7
 #endif
 
+// Division by a launch-invariant divisor as multiply-high + shift (valid for 0 <= n < 2^31): the block / thread
+// decode of the update kernels otherwise spends ~90 VALU instructions per thread in three 32-bit divisions.
+struct FastDiv { unsigned mul, shr, d; };
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f{0u, 0u, d};
+  if (d > 1) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;              // ceil(log2 d)
+    const unsigned p = 31 + l;
+    f.mul = (unsigned)(((1ull << p) + d - 1) / d);
+    f.shr = p - 32;
+  }
+  return f;
+}
+
 struct DevParams {
   int nx, ny, nk, P, P4;
   int plane;  // ny * P (floats)
@@ -55,6 +70,7 @@ struct DevParams {
   const int* src_ids2;
   // launch tiling: a block = 256 threads = 1024 consecutive x-cells of one strip of `tys` rows in one plane
   int tys, nbs, nstrips;
+  FastDiv fd_nbs, fd_P4;     // dividers for the block / thread decode
   int tys2, nbs2, nstrips2;
   int nt;                    // 1: non-temporal stores for the field outputs (working set beyond the Infinity Cache)  // tiling of the fused kernel (blocks of 4 x 63 owner groups)
   // fused soft sources (update_E) and probes (extra block of update_E / update_H)

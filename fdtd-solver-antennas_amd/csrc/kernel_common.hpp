@@ -43,12 +43,23 @@ __device__ __forceinline__ void decode_block(int nbs, int nkr, int extra, int& s
   const unsigned k = rem / (unsigned)nbs;
   strip = (int)s; kk = (int)k; pb = (int)(rem - k * (unsigned)nbs);
 }
+__device__ __forceinline__ unsigned fd_div(const unsigned n, const FastDiv& f) { return f.d == 1u ? n : __umulhi(n, f.mul) >> f.shr; }
+// the same decode with the three divisions replaced by multiply-high (two-pass kernels)
+__device__ __forceinline__ void decode_block_fd(const FastDiv& fd_ps, const FastDiv& fd_nbs, int extra, int& strip, int& kk, int& pb) {
+  const unsigned nb = gridDim.x - (unsigned)extra, b = blockIdx.x;
+  const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
+  const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  const unsigned s = fd_div(v, fd_ps);
+  const unsigned rem = v - s * fd_ps.d;
+  const unsigned k = fd_div(rem, fd_nbs);
+  strip = (int)s; kk = (int)k; pb = (int)(rem - k * fd_nbs.d);
+}
 // ... and the per-thread part.  Returns false for threads beyond the strip.
 __device__ __forceinline__ bool decode_thread(const DevParams& p, int strip, int pb, int& j, int& i0) {
   const int t = pb * FDTD_BLOCK + (int)threadIdx.x;
   const int rows = min(p.tys, p.ny - strip * p.tys);
   if (t >= rows * p.P4) return false;
-  const int jj = t / p.P4;
+  const int jj = (int)fd_div((unsigned)t, p.fd_P4);
   j = strip * p.tys + jj;
   i0 = (t - jj * p.P4) * 4;
   return true;

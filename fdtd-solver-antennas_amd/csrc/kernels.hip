@@ -33,8 +33,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // COEF: 0 raw arrays, 1 class byte per edge, 2 one packed class byte per cell
 template <int COEF, bool PML, bool FUSE>
-__global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const int nkr,
-                                                         const long long step, const int extra) {
+__global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const FastDiv fd_ps,
+                                                                            const long long step, const int extra) {
   __shared__ float2 s_lut[COEF == 2 ? 768 : (COEF == 1 ? 256 : 1)];
   __shared__ double s_red[FUSE ? FDTD_BLOCK : 1];
   __shared__ SrcStage s_src;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const
     return;
   }
   int strip, kk, pb;
-  decode_block(p.nbs, nkr, extra, strip, kk, pb);
+  decode_block_fd(fd_ps, p.fd_nbs, extra, strip, kk, pb);
   const int k = k_begin + kk;
   // coefficient table -> registers now, -> LDS after the field loads have been issued (loads return in order, so
   // waiting for these few entries leaves the field loads in flight)
@@ -180,15 +180,15 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const
 // K2: H half-step
 // ------------------------------------------------------------------------------------------------
 template <bool RAW, bool PML>
-__global__ __launch_bounds__(FDTD_BLOCK, FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const int nkr,
-                                                         const long long step, const int extra) {
+__global__ __launch_bounds__(FDTD_BLOCK, FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const FastDiv fd_ps,
+                                                                            const long long step, const int extra) {
   __shared__ double s_red[FDTD_BLOCK];
   if (extra && blockIdx.x == gridDim.x - 1) {   // probe block: V-probes of this step (V is final, H not read)
     probe_block(p, FDTD_KIND_V, step, s_red);
     return;
   }
   int strip, kk, pb, j, i0;
-  decode_block(p.nbs, nkr, extra, strip, kk, pb);
+  decode_block_fd(fd_ps, p.fd_nbs, extra, strip, kk, pb);
   const int k = k_begin + kk;
   if (!decode_thread(p, strip, pb, j, i0)) return;
   const int off = k * p.plane + j * p.P + i0;
@@ -382,11 +382,13 @@ void choose_tiling(fdtd_ctx* c) {
   c->p.tys = best;
   c->p.nbs = (best * P4 + FDTD_BLOCK - 1) / FDTD_BLOCK;
   c->p.nstrips = (ny + best - 1) / best;
+  c->p.fd_nbs = make_fastdiv((unsigned)c->p.nbs);
+  c->p.fd_P4 = make_fastdiv((unsigned)P4);
 }
 
-// Occupancy cap without recompiling: dynamic LDS padding so that at most `cap` blocks fit the CU's 160 KiB
-// (0 = no cap).  More resident waves are not always faster here: HBM-resident grids lose L2 reuse of the k-1 / j-1
-// neighbour rows when too many strips are in flight.
+// Occupancy cap without recompiling (experiments): dynamic LDS padding so that at most `cap` blocks fit the CU's
+// 160 KiB (0 = no cap).  Measured (profiles/r01/occupancy_cap_sweep.txt): throughput falls monotonically with the cap
+// on cache-resident and HBM-resident grids alike, so the default is no cap.
 static unsigned lds_pad(int cap, unsigned static_bytes) {
   if (cap <= 0) return 0;
   const unsigned total = (163840u / (unsigned)cap) & ~1023u;
@@ -396,8 +398,9 @@ static unsigned lds_pad(int cap, unsigned static_bytes) {
 template <int COEF, bool PML>
 static void launch_E2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long step, bool fused, int extra, hipStream_t s) {
   const unsigned pad = lds_pad(c->occ_e, 11264u);
-  if (fused) hipLaunchKernelGGL((k_update_E<COEF, PML, true>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, nkr, step, extra);
-  else hipLaunchKernelGGL((k_update_E<COEF, PML, false>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, nkr, step, 0);
+  const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
+  if (fused) hipLaunchKernelGGL((k_update_E<COEF, PML, true>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, fd_ps, step, extra);
+  else hipLaunchKernelGGL((k_update_E<COEF, PML, false>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, fd_ps, step, 0);
 }
 
 void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool fused, bool probe_block, hipStream_t s) {
@@ -423,12 +426,13 @@ void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool p
   const int extra = probe_block ? 1 : 0;
   const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs + extra)), block(FDTD_BLOCK);
   const unsigned pad = lds_pad(c->occ_h, 2560u);
+  const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
   if (c->raw_op) {
-    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<true, true>), grid, block, pad, s, c->p, k_begin, nkr, step, extra);
-    else hipLaunchKernelGGL((k_update_H<true, false>), grid, block, pad, s, c->p, k_begin, nkr, step, extra);
+    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<true, true>), grid, block, pad, s, c->p, k_begin, fd_ps, step, extra);
+    else hipLaunchKernelGGL((k_update_H<true, false>), grid, block, pad, s, c->p, k_begin, fd_ps, step, extra);
   } else {
-    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<false, true>), grid, block, pad, s, c->p, k_begin, nkr, step, extra);
-    else hipLaunchKernelGGL((k_update_H<false, false>), grid, block, pad, s, c->p, k_begin, nkr, step, extra);
+    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<false, true>), grid, block, pad, s, c->p, k_begin, fd_ps, step, extra);
+    else hipLaunchKernelGGL((k_update_H<false, false>), grid, block, pad, s, c->p, k_begin, fd_ps, step, extra);
   }
 }
 
