@@ -42,7 +42,7 @@ class FdtdProfile(C.Structure):
 
 FLAG_KERNEL_AUTO, FLAG_KERNEL_DIRECT, FLAG_KERNEL_FUSED, FLAG_KERNEL_TILE, FLAG_NO_GRAPH = 0, 1, 2, 3, 0x10
 FLAG_KERNEL_MARCH = 4
-FLAG_OVERLAP_ON, FLAG_OVERLAP_OFF = 0x20, 0x40
+FLAG_OVERLAP_ON, FLAG_OVERLAP_OFF, FLAG_LOOPBACK = 0x20, 0x40, 0x80
 KIND_V, KIND_I = 0, 1
 PHASE_E, PHASE_H = 0, 1
 HALO_H_UP, HALO_E_DOWN = 0, 1

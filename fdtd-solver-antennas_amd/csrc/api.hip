@@ -568,26 +568,29 @@ static int check_ready(fdtd_ctx* c) {
 static int exchange_rccl(fdtd_ctx* c, int which) {
   ncclComm_t comm = (ncclComm_t)c->comm;
   const int r = c->d.rank, w = c->d.world;
+  // FDTD_FLAG_LOOPBACK (transport self-test on one GPU): both neighbours are this rank itself, in a communicator of 1
+  const bool loop = (c->d.flags & FDTD_FLAG_LOOPBACK) != 0;
+  const int down = loop ? 0 : r - 1, up = loop ? 0 : r + 1;
   const size_t cnt = (size_t)c->plane;
   const long top = (long)(c->d.nk - 1) * c->plane;
   NCCLCK(c, ncclGroupStart());
   if (which == FDTD_HALO_E_DOWN) {
     if (r > 0) {
-      NCCLCK(c, ncclSend(c->p.V[0], cnt, ncclFloat, r - 1, comm, c->comm_stream));
-      NCCLCK(c, ncclSend(c->p.V[1], cnt, ncclFloat, r - 1, comm, c->comm_stream));
+      NCCLCK(c, ncclSend(c->p.V[0], cnt, ncclFloat, down, comm, c->comm_stream));
+      NCCLCK(c, ncclSend(c->p.V[1], cnt, ncclFloat, down, comm, c->comm_stream));
     }
     if (r < w - 1) {
-      NCCLCK(c, ncclRecv(c->p.V[0] + c->nloc, cnt, ncclFloat, r + 1, comm, c->comm_stream));
-      NCCLCK(c, ncclRecv(c->p.V[1] + c->nloc, cnt, ncclFloat, r + 1, comm, c->comm_stream));
+      NCCLCK(c, ncclRecv(c->p.V[0] + c->nloc, cnt, ncclFloat, up, comm, c->comm_stream));
+      NCCLCK(c, ncclRecv(c->p.V[1] + c->nloc, cnt, ncclFloat, up, comm, c->comm_stream));
     }
   } else {
     if (r < w - 1) {
-      NCCLCK(c, ncclSend(c->p.I[0] + top, cnt, ncclFloat, r + 1, comm, c->comm_stream));
-      NCCLCK(c, ncclSend(c->p.I[1] + top, cnt, ncclFloat, r + 1, comm, c->comm_stream));
+      NCCLCK(c, ncclSend(c->p.I[0] + top, cnt, ncclFloat, up, comm, c->comm_stream));
+      NCCLCK(c, ncclSend(c->p.I[1] + top, cnt, ncclFloat, up, comm, c->comm_stream));
     }
     if (r > 0) {
-      NCCLCK(c, ncclRecv(c->p.I[0] - c->plane, cnt, ncclFloat, r - 1, comm, c->comm_stream));
-      NCCLCK(c, ncclRecv(c->p.I[1] - c->plane, cnt, ncclFloat, r - 1, comm, c->comm_stream));
+      NCCLCK(c, ncclRecv(c->p.I[0] - c->plane, cnt, ncclFloat, down, comm, c->comm_stream));
+      NCCLCK(c, ncclRecv(c->p.I[1] - c->plane, cnt, ncclFloat, down, comm, c->comm_stream));
     }
   }
   NCCLCK(c, ncclGroupEnd());
@@ -1059,7 +1062,12 @@ int fdtd_comm_init(fdtd_ctx* c, const void* uid128) {
   ncclUniqueId id;
   memcpy(&id, uid128, 128);
   ncclComm_t comm;
-  NCCLCK(c, ncclCommInitRank(&comm, c->d.world, id, c->d.rank));
+  if (c->d.flags & FDTD_FLAG_LOOPBACK) {
+    if (c->d.rank == 0 || c->d.rank == c->d.world - 1) return fdtd_fail(c, FDTD_E_ARG, "loopback self-test needs an interior slab (0 < rank < world-1)");
+    NCCLCK(c, ncclCommInitRank(&comm, 1, id, 0));
+  } else {
+    NCCLCK(c, ncclCommInitRank(&comm, c->d.world, id, c->d.rank));
+  }
   c->comm = comm;
   return FDTD_OK;
 }

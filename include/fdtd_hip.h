@@ -76,7 +76,11 @@ enum {
   FDTD_FLAG_KERNEL_MASK   = 0xF,
   FDTD_FLAG_NO_GRAPH      = 0x10, /* reserved */
   FDTD_FLAG_OVERLAP_ON    = 0x20, /* multi-slab: split sweeps into interior + halo-dependent plane (the default) */
-  FDTD_FLAG_OVERLAP_OFF   = 0x40  /* multi-slab: one launch per sweep, after the halo has arrived */
+  FDTD_FLAG_OVERLAP_OFF   = 0x40, /* multi-slab: one launch per sweep, after the halo has arrived */
+  FDTD_FLAG_LOOPBACK      = 0x80  /* transport self-test on ONE GPU: an interior slab (0 < rank < world-1) exchanges
+                                     both halos with ITSELF — fdtd_comm_init makes a communicator of one rank and every
+                                     ncclSend/ncclRecv of the step loop is a self send/recv.  Same result as driving
+                                     fdtd_half_step + fdtd_halo_get/put back into the same context. */
 };
 
 typedef struct fdtd_ctx fdtd_ctx;

@@ -281,3 +281,43 @@ def test_northstar_acceptance(hip_lib, oracle_lib):
     assert out["tolerance"] == 1e-3
     assert out["pass"], out["rel_l2"]
     assert max(out["rel_l2"].values()) < 1e-6, out["rel_l2"]
+
+
+@pytest.mark.parametrize("overlap", ["split", "nosplit"])
+def test_rccl_self_loopback_transport(hip_lib, oracle_lib, overlap):
+    """The RCCL calls themselves on one GPU: an interior slab (rank 1 of 3) whose halos go to ITSELF through
+    ncclSend/ncclRecv in a communicator of one (FDTD_FLAG_LOOPBACK) — the library's own step loop, communication
+    stream, events and overlap split — against the same slab stepped by half-steps with its halo planes copied back
+    through the host, on the HIP library and on the oracle.  Interior planes have live coefficients on both faces, so
+    a wrong plane, component, count or ordering changes the fields."""
+    capi = pkg("_capi")
+    flag = capi.FLAG_LOOPBACK | (capi.FLAG_OVERLAP_ON if overlap == "split" else capi.FLAG_OVERLAP_OFF)
+    n = 120
+
+    def slab(lib, flags):
+        s = patch_sim(44, 40, 36, nr_ts=n + 8, nf2ff=False)
+        e = s.build(lib, rank=1, world=3, flags=flags)
+        seeded_fields(e, 11)
+        return s, e
+
+    _, er = slab(hip_lib, flag)
+    er.comm_init(capi.comm_unique_id(hip_lib))
+    er.run(n)
+    outs = [er.fields()]
+    for lib in (hip_lib, oracle_lib):
+        _, e = slab(lib, 0)
+        for _ in range(n):
+            e.half_step(capi.PHASE_E)
+            e.halo_put(capi.HALO_E_DOWN, e.halo_get(capi.HALO_E_DOWN))
+            e.half_step(capi.PHASE_H)
+            e.halo_put(capi.HALO_H_UP, e.halo_get(capi.HALO_H_UP))
+        outs.append(e.fields())
+    assert er.step == n and np.isfinite(outs[2]).all() and np.abs(outs[2]).max() > 0
+    assert same_values(outs[0], outs[1]), f"RCCL loopback vs host loopback (HIP): rel L2 {rel_l2(outs[0], outs[1]):.3e}"
+    assert same_values(outs[0], outs[2]), f"RCCL loopback vs oracle: rel L2 {rel_l2(outs[0], outs[2]):.3e}"
+    # and the loopback really matters: without any exchange the same slab ends elsewhere
+    _, e0 = slab(hip_lib, 0)
+    for _ in range(n):
+        e0.half_step(capi.PHASE_E)
+        e0.half_step(capi.PHASE_H)
+    assert not same_values(e0.fields(), outs[0])
