@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "fdtd_operator_form", "fdtd_get_operator", "fdtd_set_cpml",
     "fdtd_set_mur", "fdtd_set_signal", "fdtd_add_source", "fdtd_add_probe", "fdtd_get_probe",
     "fdtd_set_dft", "fdtd_add_dft_box", "fdtd_get_dft_box", "fdtd_run", "fdtd_run_profiled",
-    "fdtd_get_step", "fdtd_energy", "fdtd_comm_unique_id", "fdtd_comm_init", "fdtd_link", "fdtd_run_linked", "fdtd_half_step",
+    "fdtd_get_step", "fdtd_energy", "fdtd_p2p_export", "fdtd_p2p_attach", "fdtd_comm_unique_id", "fdtd_comm_init", "fdtd_link", "fdtd_run_linked", "fdtd_half_step",
     "fdtd_halo_get", "fdtd_halo_put", "fdtd_get_field", "fdtd_set_field", "fdtd_farfield",
 ]
 
@@ -78,6 +78,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
         "fdtd_run_profiled": (C.c_int, [p, C.c_int, C.POINTER(FdtdProfile)]),
         "fdtd_get_step": (C.c_int, [p, C.POINTER(C.c_int64)]),
         "fdtd_energy": (C.c_int, [p, p]),
+        "fdtd_p2p_export": (C.c_int, [p, p]),
+        "fdtd_p2p_attach": (C.c_int, [p, p, p]),
         "fdtd_comm_unique_id": (C.c_int, [p]),
         "fdtd_comm_init": (C.c_int, [p, p]),
         "fdtd_link": (C.c_int, [p, p]),
@@ -346,6 +348,19 @@ class Engine:
             raise ValueError("halo buffer must be [2][ny][nx]")
         self._ck(self.lib.fdtd_halo_put(self._ctx, int(which), _ptr(buf)), "halo_put")
 
+    def p2p_export(self) -> bytes:
+        """128-byte description of this context's halo mailbox (IPC handle) for the neighbour ranks."""
+        buf = C.create_string_buffer(128)
+        self._ck(self.lib.fdtd_p2p_export(self._ctx, buf), "p2p_export")
+        return buf.raw
+
+    def p2p_attach(self, lower: Optional[bytes], upper: Optional[bytes]):
+        """Attach the mailboxes of rank-1 / rank+1 (None where there is no neighbour): halos then travel inside the
+        update kernels (csrc/kernels.hip, P2P variants)."""
+        lo = C.create_string_buffer(lower, 128) if lower is not None else None
+        hi = C.create_string_buffer(upper, 128) if upper is not None else None
+        self._ck(self.lib.fdtd_p2p_attach(self._ctx, lo, hi), "p2p_attach")
+
     def comm_init(self, uid: bytes):
         if len(uid) != 128:
             raise ValueError("unique id must be 128 bytes")
@@ -367,6 +382,11 @@ class Engine:
     def fields(self):
         """All six components as [2][3][nk][ny][nx]."""
         return np.stack([np.stack([self.get_field(kind, c) for c in range(3)]) for kind in (KIND_V, KIND_I)])
+
+
+def link(lower, upper):
+    """fdtd_link: adjacent slabs of one process (or one FDTD_FLAG_LOOPBACK slab with itself)."""
+    lower._ck(lower.lib.fdtd_link(lower._ctx, upper._ctx), "link")
 
 
 def run_linked(engines, nsteps: int):

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <vector>
@@ -220,6 +221,9 @@ void fdtd_destroy(fdtd_ctx* c) {
   hipFree(c->d_energy); hipFree(c->src_rng); hipFree(c->src_ids); hipFree(c->src_rng2); hipFree(c->src_ids2);
   hipFree(c->src_rng3); hipFree(c->src_ids3); hipFree(c->src_rng4); hipFree(c->src_ids4);
   for (int n = 0; n < 6; ++n) { hipFree(c->fieldbase2[n]); hipFree(c->psi2[n]); }
+  if (c->peer_lo && c->peer_lo_ipc) hipIpcCloseMemHandle(c->peer_lo);
+  if (c->peer_hi && c->peer_hi_ipc) hipIpcCloseMemHandle(c->peer_hi);
+  hipFree(c->mbox);
   if (c->ev_E) hipEventDestroy(c->ev_E);
   if (c->ev_H) hipEventDestroy(c->ev_H);
   if (c->ev_haloE) hipEventDestroy(c->ev_haloE);
@@ -791,6 +795,8 @@ static int phase_H(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
 }
 
 static int step_loop_fused(fdtd_ctx* c, int nsteps, struct ProfEvents* pe);
+static int step_loop_p2p(fdtd_ctx* c, int nsteps, struct ProfEvents* pe);
+static int p2p_check(fdtd_ctx* c);
 
 static bool one_pass_mode(unsigned kmode) {
   return kmode == FDTD_FLAG_KERNEL_FUSED || kmode == FDTD_FLAG_KERNEL_TILE || kmode == FDTD_FLAG_KERNEL_MARCH;
@@ -803,8 +809,9 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   // AUTO currently resolves to the two-pass kernels (faster on MI355X as measured, profiles/r01); the
   // one-pass kernel is opt-in until it shares neighbours through LDS.
   if (one_pass_mode(kmode)) return step_loop_fused(c, nsteps, pe);
+  if (c->p.p2p) return step_loop_p2p(c, nsteps, pe);
   const bool multi = c->d.world > 1;
-  if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
+  if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_p2p_attach (mailbox transport), fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
   const bool fused = !c->any_mur;
   for (int n = 0; n < nsteps; ++n) {
     int r = phase_E(c, multi, fused, pe, n);
@@ -815,6 +822,36 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
     c->step++;
   }
   if (fused && nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);   // flush the last step's I-probes
+  HIPCK(c, hipGetLastError());
+  return FDTD_OK;
+}
+
+// P2P mailbox transport: the halos travel inside the update kernels, so a step is two launches on ONE stream —
+// no communication stream, no events, no RCCL call; neighbouring ranks couple only through the mailbox flags.
+static int p2p_enqueue_E(fdtd_ctx* c, ProfEvents* pe, int n) {
+  HIPCK(c, hipSetDevice(c->d.device));
+  if (pe) HIPCK(c, hipEventRecord(pe->e0[n], c->stream));
+  launch_update_E(c, 0, c->d.nk, c->step, true, true, c->stream);
+  if (pe) HIPCK(c, hipEventRecord(pe->e1[n], c->stream));
+  launch_dft(c, FDTD_KIND_V, c->step, c->stream);
+  return FDTD_OK;
+}
+static int p2p_enqueue_H(fdtd_ctx* c, ProfEvents* pe, int n) {
+  HIPCK(c, hipSetDevice(c->d.device));
+  if (pe) HIPCK(c, hipEventRecord(pe->h0[n], c->stream));
+  launch_update_H(c, 0, c->d.nk, c->step, true, c->stream);
+  if (pe) HIPCK(c, hipEventRecord(pe->h1[n], c->stream));
+  launch_dft(c, FDTD_KIND_I, c->step, c->stream);
+  return FDTD_OK;
+}
+static int step_loop_p2p(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
+  if (c->any_mur || c->d.nk < 2) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "p2p transport: needs >= 2 planes per slab and no Mur faces");
+  for (int n = 0; n < nsteps; ++n) {
+    int r;
+    if ((r = p2p_enqueue_E(c, pe, n)) || (r = p2p_enqueue_H(c, pe, n))) return r;
+    c->step++;
+  }
+  if (nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);   // flush the last step's I-probes
   HIPCK(c, hipGetLastError());
   return FDTD_OK;
 }
@@ -856,6 +893,7 @@ int fdtd_run(fdtd_ctx* c, int nsteps) {
   if (r) return r;
   HIPCK(c, hipStreamSynchronize(c->stream));
   HIPCK(c, hipStreamSynchronize(c->comm_stream));
+  if (c->p.p2p) return p2p_check(c);
   return FDTD_OK;
 }
 
@@ -993,8 +1031,98 @@ int fdtd_halo_put(fdtd_ctx* c, int which, const float* buf) {
 }
 
 // ---- in-process transport: several slabs driven by one host thread ---------------------------------------
+// ---- P2P mailbox transport ----------------------------------------------------------------------------------
+// Mailbox of a context: [E: 2 parities x 2 comps x plane][H: the same] floats, then 64 control words:
+// [0] E halos received, [1] H halos received, [2],[3] arrival counters, [4] error word, [8..] self-test slots.
+struct P2pBlob { hipIpcMemHandle_t h; uint64_t bytes; uint64_t raw; int32_t pid, device, nx, ny; };
+static_assert(sizeof(P2pBlob) <= 128, "blob must fit the 128-byte exchange buffer");
+
+static size_t p2p_floats(const fdtd_ctx* c) { return (size_t)8 * c->plane; }
+
+static int p2p_alloc(fdtd_ctx* c) {
+  if (c->mbox) return FDTD_OK;
+  HIPCK(c, hipSetDevice(c->d.device));
+  c->mbox_bytes = p2p_floats(c) * sizeof(float) + 64 * sizeof(unsigned);
+  HIPCK(c, hipMalloc(&c->mbox, c->mbox_bytes));
+  HIPCK(c, hipMemset(c->mbox, 0, c->mbox_bytes));
+  return FDTD_OK;
+}
+
+static void p2p_views(const fdtd_ctx* c, void* base, float** in_E, float** in_H, unsigned** ctl) {
+  float* f = (float*)base;
+  *in_E = f; *in_H = f + 4 * (size_t)c->plane; *ctl = (unsigned*)(f + p2p_floats(c));
+}
+
+int fdtd_p2p_export(fdtd_ctx* c, void* out128) {
+  if (!c || !out128) return FDTD_E_ARG;
+  int r = p2p_alloc(c);
+  if (r) return r;
+  P2pBlob b{};
+  HIPCK(c, hipIpcGetMemHandle(&b.h, c->mbox));
+  b.bytes = c->mbox_bytes; b.raw = (uint64_t)(uintptr_t)c->mbox; b.pid = (int32_t)getpid(); b.device = c->d.device;
+  b.nx = c->d.nx; b.ny = c->d.ny;
+  memset(out128, 0, 128);
+  memcpy(out128, &b, sizeof(b));
+  return FDTD_OK;
+}
+
+static int p2p_open(fdtd_ctx* c, const void* blob128, void** out, bool* ipc) {
+  P2pBlob b;
+  memcpy(&b, blob128, sizeof(b));
+  if (b.nx != c->d.nx || b.ny != c->d.ny || b.bytes != c->mbox_bytes) return fdtd_fail(c, FDTD_E_ARG, "p2p: neighbour mailbox belongs to another grid");
+  if (b.pid == (int32_t)getpid()) { *out = (void*)(uintptr_t)b.raw; *ipc = false; return FDTD_OK; }   // same process: the pointer itself
+  HIPCK(c, hipIpcOpenMemHandle(out, b.h, hipIpcMemLazyEnablePeerAccess));
+  *ipc = true;
+  return FDTD_OK;
+}
+
+// lower128 / upper128: blobs exported by ranks rank-1 / rank+1 (null where there is no such neighbour)
+int fdtd_p2p_attach(fdtd_ctx* c, const void* lower128, const void* upper128) {
+  if (!c) return FDTD_E_ARG;
+  if (c->d.world < 2) return fdtd_fail(c, FDTD_E_ARG, "p2p transport needs world > 1");
+  if ((c->d.rank > 0) != (lower128 != nullptr) || (c->d.rank < c->d.world - 1) != (upper128 != nullptr))
+    return fdtd_fail(c, FDTD_E_ARG, "p2p: rank %d of %d needs exactly its existing neighbours' blobs", c->d.rank, c->d.world);
+  if (c->comm || c->link_lo || c->link_hi) return fdtd_fail(c, FDTD_E_STATE, "p2p: another halo transport is already attached");
+  int r = p2p_alloc(c);
+  if (r) return r;
+  HIPCK(c, hipSetDevice(c->d.device));
+  if (lower128 && (r = p2p_open(c, lower128, &c->peer_lo, &c->peer_lo_ipc))) return r;
+  if (upper128 && (r = p2p_open(c, upper128, &c->peer_hi, &c->peer_hi_ipc))) return r;
+  float *in_E, *in_H; unsigned* ctl;
+  p2p_views(c, c->mbox, &in_E, &in_H, &ctl);
+  DevParams& p = c->p;
+  p.mb_in_E = upper128 ? in_E : nullptr;
+  p.mb_in_H = lower128 ? in_H : nullptr;
+  p.fl_in = ctl; p.p2p_cnt = ctl + 2; p.p2p_err = (int*)(ctl + 4);
+  p.mb_out_E = nullptr; p.mb_out_H = nullptr; p.fl_out_E = nullptr; p.fl_out_H = nullptr;
+  if (c->peer_lo) { float *e, *h; unsigned* f; p2p_views(c, c->peer_lo, &e, &h, &f); p.mb_out_E = e; p.fl_out_E = f + 0; }
+  if (c->peer_hi) { float *e, *h; unsigned* f; p2p_views(c, c->peer_hi, &e, &h, &f); p.mb_out_H = h; p.fl_out_H = f + 1; }
+  int waves = 0;   // waves with a valid thread among the blocks of one plane
+  for (int s = 0; s < p.nstrips; ++s) {
+    const int rows = std::min(p.tys, p.ny - s * p.tys);
+    waves += (rows * p.P4 + 63) / 64;
+  }
+  p.p2p_waves = waves;
+  p.p2p = 1;
+  return FDTD_OK;
+}
+
+static int p2p_check(fdtd_ctx* c) {
+  int err = 0;
+  HIPCK(c, hipMemcpy(&err, c->p.p2p_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (err) return fdtd_fail(c, FDTD_E_DEVICE, "p2p: a halo wait timed out (neighbour rank not stepping, or peer memory not visible)");
+  return FDTD_OK;
+}
+
 int fdtd_link(fdtd_ctx* lower, fdtd_ctx* upper) {
   if (!lower || !upper) return FDTD_E_ARG;
+  if (lower == upper) {   // FDTD_FLAG_LOOPBACK: an interior slab linked to itself (transport self-test / timing)
+    fdtd_ctx* c = lower;
+    if (!(c->d.flags & FDTD_FLAG_LOOPBACK) || c->d.rank == 0 || c->d.rank == c->d.world - 1)
+      return fdtd_fail(c, FDTD_E_ARG, "fdtd_link(c, c) needs FDTD_FLAG_LOOPBACK on an interior slab");
+    c->link_lo = c->link_hi = c;
+    return FDTD_OK;
+  }
   if (lower->d.world != upper->d.world || upper->d.rank != lower->d.rank + 1 || lower->d.k0 + lower->d.nk != upper->d.k0 ||
       lower->d.nx != upper->d.nx || lower->d.ny != upper->d.ny)
     return fdtd_fail(lower, FDTD_E_ARG, "fdtd_link: contexts are not adjacent slabs of one grid");
@@ -1017,11 +1145,34 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
     fdtd_ctx* c = ctxs[r];
     int rc = check_ready(c);
     if (rc) return rc;
+    const bool loop = n == 1 && (c->d.flags & FDTD_FLAG_LOOPBACK) && c->link_lo == c && c->link_hi == c;
+    if (loop) { if (c->comm) return fdtd_fail(c, FDTD_E_ARG, "loopback: linked and RCCL transports are exclusive"); continue; }
     if (c->d.world != n || c->d.rank != r || c->comm) return fdtd_fail(c, FDTD_E_ARG, "fdtd_run_linked: contexts must be ranks 0..n-1 of a world of n without an RCCL communicator");
-    if ((r > 0 && c->link_lo != ctxs[r - 1]) || (r < n - 1 && c->link_hi != ctxs[r + 1])) return fdtd_fail(c, FDTD_E_STATE, "fdtd_run_linked: call fdtd_link on every adjacent pair first");
+    if (!c->p.p2p && ((r > 0 && c->link_lo != ctxs[r - 1]) || (r < n - 1 && c->link_hi != ctxs[r + 1]))) return fdtd_fail(c, FDTD_E_STATE, "fdtd_run_linked: call fdtd_link (or fdtd_p2p_attach) on every adjacent pair first");
     if (one_pass_mode(c->d.flags & FDTD_FLAG_KERNEL_MASK)) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "one-pass kernels are single-slab");
   }
-  const bool multi = n > 1;
+  const bool multi = n > 1 || (ctxs[0]->d.flags & FDTD_FLAG_LOOPBACK);
+  if (ctxs[0]->p.p2p) {   // mailbox transport between contexts of this process: interleave the ranks' launches
+    for (int r = 0; r < n; ++r) if (!ctxs[r]->p.p2p || ctxs[r]->any_mur) return fdtd_fail(ctxs[r], FDTD_E_STATE, "fdtd_run_linked: every context must use the p2p transport (no Mur)");
+    for (int s = 0; s < nsteps; ++s) {
+      int rc;
+      for (int r = 0; r < n; ++r) if ((rc = p2p_enqueue_E(ctxs[r], nullptr, 0))) return rc;
+      for (int r = 0; r < n; ++r) { if ((rc = p2p_enqueue_H(ctxs[r], nullptr, 0))) return rc; ctxs[r]->step++; }
+    }
+    for (int r = 0; r < n; ++r) {
+      fdtd_ctx* c = ctxs[r];
+      HIPCK(c, hipSetDevice(c->d.device));
+      if (nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);
+    }
+    for (int r = 0; r < n; ++r) {
+      fdtd_ctx* c = ctxs[r];
+      HIPCK(c, hipSetDevice(c->d.device));
+      HIPCK(c, hipStreamSynchronize(c->stream));
+      int rc = p2p_check(c);
+      if (rc) return rc;
+    }
+    return FDTD_OK;
+  }
   for (int s = 0; s < nsteps; ++s) {
     int rc;
     for (int r = 0; r < n; ++r) if ((rc = phase_E(ctxs[r], multi, !ctxs[r]->any_mur, nullptr, 0))) return rc;

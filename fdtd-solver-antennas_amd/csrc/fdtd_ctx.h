@@ -71,6 +71,17 @@ struct DevParams {
   // launch tiling: a block = 256 threads = 1024 consecutive x-cells of one strip of `tys` rows in one plane
   int tys, nbs, nstrips;
   FastDiv fd_nbs, fd_P4;     // dividers for the block / thread decode
+  // P2P mailbox halo transport (in-kernel pushes over xGMI / peer mappings; no streams, events or RCCL in the step loop).
+  // Mailbox layout (one allocation per context, zero at start): [E: 2 parities][2 comps][plane] floats, then the same
+  // for H, then flags.  mb_in_*: my own mailbox; mb_out_*: the neighbour's (peer pointer), null without that neighbour.
+  int p2p;                   // 1: the update kernels run the mailbox protocol
+  int p2p_waves;             // waves with at least one valid thread in one plane of blocks (arrival count of a push)
+  float* mb_in_E; float* mb_in_H;     // V x,y of the upper neighbour's plane 0 / I x,y of the lower neighbour's top plane
+  float* mb_out_E; float* mb_out_H;   // lower neighbour's mb_in_E / upper neighbour's mb_in_H
+  unsigned* fl_in;           // [0]: E halos received (= step + 1 of the newest), [1]: H halos received
+  unsigned* fl_out_E; unsigned* fl_out_H;   // &lower->fl_in[0], &upper->fl_in[1]
+  unsigned* p2p_cnt;         // local arrival counters [2]
+  int* p2p_err;              // set when a halo wait timed out
   int tys2, nbs2, nstrips2;
   int nt;                    // 1: non-temporal stores for the field outputs (working set beyond the Infinity Cache)  // tiling of the fused kernel (blocks of 4 x 63 owner groups)
   // fused soft sources (update_E) and probes (extra block of update_E / update_H)
@@ -97,6 +108,10 @@ struct fdtd_ctx {
   int2* src_rng2 = nullptr; int* src_ids2 = nullptr;
   int2* src_rng3 = nullptr; int* src_ids3 = nullptr;
   int2* src_rng4 = nullptr; int* src_ids4 = nullptr;
+  // P2P mailbox transport
+  void* mbox = nullptr; size_t mbox_bytes = 0;     // my mailbox allocation
+  void* peer_lo = nullptr; void* peer_hi = nullptr; // neighbours' mailboxes (IPC mappings or in-process pointers)
+  bool peer_lo_ipc = false, peer_hi_ipc = false;
   int occ_e = 0, occ_h = 0;      // cap on resident blocks per CU of update_E / update_H (0: none); $FDTD_OCC_E / $FDTD_OCC_H
   int march_kc = 0;              // z-marching kernel: planes per chunk ($FDTD_MARCH_KC, default 10)
   bool fused_ready = false;

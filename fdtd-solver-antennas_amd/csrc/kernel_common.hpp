@@ -54,6 +54,59 @@ __device__ __forceinline__ void decode_block_fd(const FastDiv& fd_ps, const Fast
   const unsigned k = fd_div(rem, fd_nbs);
   strip = (int)s; kk = (int)k; pb = (int)(rem - k * fd_nbs.d);
 }
+// ---- P2P mailbox protocol -------------------------------------------------------------------------------------------
+// system-scope loads (bypass this XCD's L2, which may hold the mailbox lines of two steps ago)
+__device__ __forceinline__ float4 ld4_sys(const float* q) {
+  return make_float4(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
+                     __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+// One lane per wave polls the flag until it reaches `need` (bounded: ~2 s of the 100 MHz wall clock, then the error
+// word is set and the wave goes on with whatever the mailbox holds); acquire at system scope afterwards.
+__device__ __forceinline__ void p2p_wait(const unsigned* flag, const unsigned need, int* err) {
+  const unsigned long long m = __ballot(1);
+  if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 200000000ull) { *err = 1; break; }
+    }
+  }
+  __threadfence_system();   // acquire: nothing below may be satisfied from before the flag was seen
+}
+// After a wave has stored its part of a halo into the neighbour's mailbox: release at system scope, count the wave;
+// the wave that completes the plane publishes flag = value to the neighbour.
+__device__ __forceinline__ void p2p_arrive(unsigned* cnt, const unsigned total, unsigned* flag, const unsigned value) {
+  __threadfence_system();
+  const unsigned long long m = __ballot(1);
+  if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
+    const unsigned old = atomicAdd(cnt, 1u);
+    if (old == total - 1u) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+// Block decode of the P2P launches: all planes but the halo-dependent one first (strip-major as usual), the
+// dependent plane's blocks last in dispatch order, where they wait for the neighbour without holding up the rest.
+// dep_plane: 0 for update_E (then the main part covers planes 1..), nk-1 for update_H (main part planes 0..nk-2).
+__device__ __forceinline__ void decode_block_p2p(const FastDiv& fd_ps, const FastDiv& fd_nbs, int extra, unsigned nb_main, int dep_plane,
+                                                 int main_first, int& strip, int& k, int& pb) {
+  const unsigned nb = gridDim.x - (unsigned)extra, b = blockIdx.x;
+  const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
+  const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  if (v < nb_main) {
+    const unsigned s = fd_div(v, fd_ps);
+    const unsigned rem = v - s * fd_ps.d;
+    const unsigned kk = fd_div(rem, fd_nbs);
+    strip = (int)s; k = main_first + (int)kk; pb = (int)(rem - kk * fd_nbs.d);
+  } else {
+    const unsigned w = v - nb_main;
+    const unsigned s = fd_div(w, fd_nbs);
+    strip = (int)s; k = dep_plane; pb = (int)(w - s * fd_nbs.d);
+  }
+}
+
 // ... and the per-thread part.  Returns false for threads beyond the strip.
 __device__ __forceinline__ bool decode_thread(const DevParams& p, int strip, int pb, int& j, int& i0) {
   const int t = pb * FDTD_BLOCK + (int)threadIdx.x;

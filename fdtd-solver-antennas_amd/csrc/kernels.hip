@@ -32,9 +32,9 @@ namespace {
 // K1: E half-step
 // ------------------------------------------------------------------------------------------------
 // COEF: 0 raw arrays, 1 class byte per edge, 2 one packed class byte per cell
-template <int COEF, bool PML, bool FUSE>
+template <int COEF, bool PML, bool FUSE, bool P2P>
 __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const FastDiv fd_ps,
-                                                                            const long long step, const int extra) {
+                                                                            const long long step, const int extra, const unsigned nb_main) {
   __shared__ float2 s_lut[COEF == 2 ? 768 : (COEF == 1 ? 256 : 1)];
   __shared__ double s_red[FUSE ? FDTD_BLOCK : 1];
   __shared__ SrcStage s_src;
@@ -42,9 +42,13 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const
     probe_block(p, FDTD_KIND_I, step - 1, s_red);
     return;
   }
-  int strip, kk, pb;
-  decode_block_fd(fd_ps, p.fd_nbs, extra, strip, kk, pb);
-  const int k = k_begin + kk;
+  int strip, kk, pb, k;
+  if (P2P) {   // all planes in one launch, the halo-dependent bottom plane last
+    decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, 0, 1, strip, k, pb);
+  } else {
+    decode_block_fd(fd_ps, p.fd_nbs, extra, strip, kk, pb);
+    k = k_begin + kk;
+  }
   // coefficient table -> registers now, -> LDS after the field loads have been issued (loads return in order, so
   // waiting for these few entries leaves the field loads in flight)
   constexpr int NLUT = COEF == 2 ? 768 : (COEF == 1 ? 256 : 0);
@@ -66,7 +70,10 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const
   const float *I0 = p.I[0] - p.plane, *I1 = p.I[1] - p.plane, *I2 = p.I[2] - p.plane;
   const float4 ix = ldo4(I0, uo), iy = ldo4(I1, uo), iz = ldo4(I2, uo);
   const float4 iz_jm = ldo4(I2, uo - p.P), ix_jm = ldo4(I0, uo - p.P);
-  const float4 iy_km = ldo4(I1, uo - p.plane), ix_km = ldo4(I0, uo - p.plane);
+  // P2P: the k-1 neighbours of the bottom plane are the lower rank's top plane and come from the mailbox (below)
+  const bool dep_in = P2P && k == 0 && p.mb_in_H != nullptr;
+  float4 iy_km = make_float4(0.f, 0.f, 0.f, 0.f), ix_km = iy_km;
+  if (!dep_in) { iy_km = ldo4(I1, uo - p.plane); ix_km = ldo4(I0, uo - p.plane); }
   const float iz_im = ldo1(I2, uo - 1), iy_im = ldo1(I1, uo - 1);
   float4 vx = ldo4(p.V[0], (unsigned)off), vy = ldo4(p.V[1], (unsigned)off), vz = ldo4(p.V[2], (unsigned)off);
   // soft sources inside this strip-plane (block-uniform range; almost always empty)
@@ -82,6 +89,12 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const
   }
   if (COEF != 0 || (FUSE && p.nsrc > 0)) __syncthreads();
   if (!valid) return;
+  if (dep_in) {   // H halo of step-1 (flag value = steps delivered); parity of the step that produced it
+    p2p_wait(p.fl_in + 1, (unsigned)step, p.p2p_err);
+    const float* mb = p.mb_in_H + (size_t)((step + 1) & 1) * 2 * p.plane + (j * p.P + i0);
+    ix_km = ld4_sys(mb);
+    iy_km = ld4_sys(mb + p.plane);
+  }
 
   // component x: d1 along y (of Iz), d2 along z (of Iy); y: d1 along z (Ix), d2 along x (Iz);
   // z: d1 along x (Iy), d2 along y (Ix)
@@ -174,31 +187,49 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const
   sto4s(p.nt, p.V[0], (unsigned)off, vx);
   sto4s(p.nt, p.V[1], (unsigned)off, vy);
   sto4s(p.nt, p.V[2], (unsigned)off, vz);
+  if (P2P && k == 0 && p.mb_out_E != nullptr) {   // push the new Vx, Vy of the bottom plane into the lower rank's mailbox
+    float* mb = p.mb_out_E + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
+    st4(mb, vx);
+    st4(mb + p.plane, vy);
+    p2p_arrive(p.p2p_cnt + 0, (unsigned)p.p2p_waves, p.fl_out_E, (unsigned)step + 1u);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // K2: H half-step
 // ------------------------------------------------------------------------------------------------
-template <bool RAW, bool PML>
+template <bool RAW, bool PML, bool P2P>
 __global__ __launch_bounds__(FDTD_BLOCK, FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const FastDiv fd_ps,
-                                                                            const long long step, const int extra) {
+                                                                            const long long step, const int extra, const unsigned nb_main) {
   __shared__ double s_red[FDTD_BLOCK];
   if (extra && blockIdx.x == gridDim.x - 1) {   // probe block: V-probes of this step (V is final, H not read)
     probe_block(p, FDTD_KIND_V, step, s_red);
     return;
   }
-  int strip, kk, pb, j, i0;
-  decode_block_fd(fd_ps, p.fd_nbs, extra, strip, kk, pb);
-  const int k = k_begin + kk;
+  int strip, kk, pb, j, i0, k;
+  if (P2P) {   // all planes in one launch, the halo-dependent top plane last
+    decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, p.nk - 1, 0, strip, k, pb);
+  } else {
+    decode_block_fd(fd_ps, p.fd_nbs, extra, strip, kk, pb);
+    k = k_begin + kk;
+  }
   if (!decode_thread(p, strip, pb, j, i0)) return;
   const int off = k * p.plane + j * p.P + i0;
 
   const unsigned uo = (unsigned)off;     // H reads planes k, k+1 only: offsets from plane 0 are never negative
   const float4 vx = ldo4(p.V[0], uo), vy = ldo4(p.V[1], uo), vz = ldo4(p.V[2], uo);
   const float4 vz_jp = ldo4(p.V[2], uo + p.P), vx_jp = ldo4(p.V[0], uo + p.P);
-  const float4 vy_kp = ldo4(p.V[1], uo + p.plane), vx_kp = ldo4(p.V[0], uo + p.plane);
+  const bool dep_in = P2P && k == p.nk - 1 && p.mb_in_E != nullptr;   // k+1 is the upper rank's bottom plane: mailbox
+  float4 vy_kp = make_float4(0.f, 0.f, 0.f, 0.f), vx_kp = vy_kp;
+  if (!dep_in) { vy_kp = ldo4(p.V[1], uo + p.plane); vx_kp = ldo4(p.V[0], uo + p.plane); }
   const float vz_ip = ldo1(p.V[2], uo + 4), vy_ip = ldo1(p.V[1], uo + 4);
   float4 ix = ldo4(p.I[0], uo), iy = ldo4(p.I[1], uo), iz = ldo4(p.I[2], uo);
+  if (dep_in) {   // E halo of this step
+    p2p_wait(p.fl_in + 0, (unsigned)step + 1u, p.p2p_err);
+    const float* mb = p.mb_in_E + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
+    vx_kp = ld4_sys(mb);
+    vy_kp = ld4_sys(mb + p.plane);
+  }
 
   float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);
   float4 dy1 = sub4(vx, vx_kp);
@@ -248,6 +279,12 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_H_MINBLOCKS) void k_update_H(const
   sto4s(p.nt, p.I[0], uo, ix);
   sto4s(p.nt, p.I[1], uo, iy);
   sto4s(p.nt, p.I[2], uo, iz);
+  if (P2P && k == p.nk - 1 && p.mb_out_H != nullptr) {   // push the new Ix, Iy of the top plane into the upper rank's mailbox
+    float* mb = p.mb_out_H + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
+    st4(mb, ix);
+    st4(mb + p.plane, iy);
+    p2p_arrive(p.p2p_cnt + 1, (unsigned)p.p2p_waves, p.fl_out_H, (unsigned)step + 1u);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -398,9 +435,15 @@ static unsigned lds_pad(int cap, unsigned static_bytes) {
 template <int COEF, bool PML>
 static void launch_E2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long step, bool fused, int extra, hipStream_t s) {
   const unsigned pad = lds_pad(c->occ_e, 11264u);
+  if (c->p.p2p) {   // whole slab in one launch, bottom plane last (decode_block_p2p)
+    const FastDiv fd_ps = make_fastdiv((unsigned)(nkr - 1) * (unsigned)c->p.nbs);
+    const unsigned nb_main = (unsigned)c->p.nstrips * (unsigned)(nkr - 1) * (unsigned)c->p.nbs;
+    hipLaunchKernelGGL((k_update_E<COEF, PML, true, true>), grid, dim3(FDTD_BLOCK), pad, s, c->p, 0, fd_ps, step, extra, nb_main);
+    return;
+  }
   const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
-  if (fused) hipLaunchKernelGGL((k_update_E<COEF, PML, true>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, fd_ps, step, extra);
-  else hipLaunchKernelGGL((k_update_E<COEF, PML, false>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, fd_ps, step, 0);
+  if (fused) hipLaunchKernelGGL((k_update_E<COEF, PML, true, false>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, fd_ps, step, extra, 0u);
+  else hipLaunchKernelGGL((k_update_E<COEF, PML, false, false>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, fd_ps, step, 0, 0u);
 }
 
 void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool fused, bool probe_block, hipStream_t s) {
@@ -420,19 +463,30 @@ void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool f
   }
 }
 
+template <bool RAW, bool PML>
+static void launch_H2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long step, int extra, hipStream_t s) {
+  const unsigned pad = lds_pad(c->occ_h, 2560u);
+  if (c->p.p2p) {
+    const FastDiv fd_ps = make_fastdiv((unsigned)(nkr - 1) * (unsigned)c->p.nbs);
+    const unsigned nb_main = (unsigned)c->p.nstrips * (unsigned)(nkr - 1) * (unsigned)c->p.nbs;
+    hipLaunchKernelGGL((k_update_H<RAW, PML, true>), grid, dim3(FDTD_BLOCK), pad, s, c->p, 0, fd_ps, step, extra, nb_main);
+    return;
+  }
+  const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
+  hipLaunchKernelGGL((k_update_H<RAW, PML, false>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, fd_ps, step, extra, 0u);
+}
+
 void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s) {
   const int nkr = k_end - k_begin;
   if (nkr <= 0) return;
   const int extra = probe_block ? 1 : 0;
-  const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs + extra)), block(FDTD_BLOCK);
-  const unsigned pad = lds_pad(c->occ_h, 2560u);
-  const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
+  const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs + extra));
   if (c->raw_op) {
-    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<true, true>), grid, block, pad, s, c->p, k_begin, fd_ps, step, extra);
-    else hipLaunchKernelGGL((k_update_H<true, false>), grid, block, pad, s, c->p, k_begin, fd_ps, step, extra);
+    if (c->have_cpml) launch_H2<true, true>(c, grid, k_begin, nkr, step, extra, s);
+    else launch_H2<true, false>(c, grid, k_begin, nkr, step, extra, s);
   } else {
-    if (c->have_cpml) hipLaunchKernelGGL((k_update_H<false, true>), grid, block, pad, s, c->p, k_begin, fd_ps, step, extra);
-    else hipLaunchKernelGGL((k_update_H<false, false>), grid, block, pad, s, c->p, k_begin, fd_ps, step, extra);
+    if (c->have_cpml) launch_H2<false, true>(c, grid, k_begin, nkr, step, extra, s);
+    else launch_H2<false, false>(c, grid, k_begin, nkr, step, extra, s);
   }
 }
 

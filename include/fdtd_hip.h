@@ -198,6 +198,16 @@ int fdtd_energy(fdtd_ctx* ctx, double sums[2]);
  *     128 bytes to every rank (e.g. torch.distributed broadcast), every rank calls comm_init. */
 int fdtd_comm_unique_id(void* out128);
 int fdtd_comm_init(fdtd_ctx* ctx, const void* uid128);
+/* (a0) P2P mailbox transport — the default for one process per GPU: the update kernels push the outgoing halo plane
+ *      straight into the neighbour's mailbox (peer / IPC mapping, xGMI stores) and publish a step counter there; the
+ *      neighbour's kernel waits for the counter before it touches the halo-dependent plane, which it schedules last.
+ *      A timestep is then two launches on one stream: no communication stream, no events, no RCCL call.  Measured
+ *      on MI355X, an 8-plane slab of the north-star grid steps in ~80 us with grouped ncclSend/ncclRecv (or peer copies)
+ *      ordered by events on a second stream, however small the slab — the reason for this transport.
+ *      Every rank exports a 128-byte blob, the host program ships the blobs (e.g. torch.distributed all_gather),
+ *      every rank attaches its neighbours' blobs (null where there is none).  Needs >= 2 planes per slab, no Mur. */
+int fdtd_p2p_export(fdtd_ctx* ctx, void* out128);
+int fdtd_p2p_attach(fdtd_ctx* ctx, const void* lower128, const void* upper128);
 /* (a') Several slabs inside ONE process (one host thread driving several GPUs, or several slabs on one GPU):
  *      link adjacent contexts, then step them together; halos move by peer copies on the communication
  *      streams with the same overlapped schedule as the RCCL path. ctxs[r] must be rank r of a world of n. */

@@ -321,3 +321,43 @@ def test_rccl_self_loopback_transport(hip_lib, oracle_lib, overlap):
         e0.half_step(capi.PHASE_E)
         e0.half_step(capi.PHASE_H)
     assert not same_values(e0.fields(), outs[0])
+
+
+def _attach_p2p(engs):
+    blobs = [e.p2p_export() for e in engs]
+    for r, e in enumerate(engs):
+        e.p2p_attach(blobs[r - 1] if r > 0 else None, blobs[r + 1] if r + 1 < len(engs) else None)
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_p2p_mailbox_transport_slabs_equal_one_slab(hip_lib, world):
+    """P2P mailbox transport (halos pushed by the update kernels into the neighbour's mailbox, step-counter flags,
+    dependent plane scheduled last): `world` slabs in this process on one GPU — each on its own stream, coupled only
+    through the mailboxes — must reproduce the single-slab run bit for bit, over several fdtd_run_linked calls."""
+    capi = pkg("_capi")
+    s1 = patch_sim(56, 52, 34, nr_ts=260)
+    e1 = s1.build(hip_lib)
+    e1.run(260)
+    sims = [patch_sim(56, 52, 34, nr_ts=260) for _ in range(world)]
+    engs = [s.build(hip_lib, rank=r, world=world) for r, s in enumerate(sims)]
+    _attach_p2p(engs)
+    for n in (1, 100, 159):
+        capi.run_linked(engs, n)
+    f2 = np.concatenate([e.fields() for e in engs], axis=2)
+    assert np.array_equal(e1.fields().view(np.uint32), f2.view(np.uint32))
+    u1, i1 = s1.port_series()[0]
+    u2 = sum(s.port_series()[0][0] for s in sims)
+    i2 = sum(s.port_series()[0][1] for s in sims)
+    assert rel_l2(u2, u1) < 1e-12 and rel_l2(i2, i1) < 1e-12
+    for a, *parts in zip(s1.nf2ff_boxes(), *[s.nf2ff_boxes() for s in sims]):
+        assert rel_l2(sum(parts), a) < 1e-12
+
+
+def test_p2p_wait_times_out_instead_of_hanging(hip_lib):
+    """A rank whose neighbour never steps: the bounded halo wait gives up after ~2 s and fdtd_run reports it."""
+    capi = pkg("_capi")
+    sims = [patch_sim(40, 36, 24, nr_ts=20, nf2ff=False) for _ in range(2)]
+    engs = [s.build(hip_lib, rank=r, world=2) for r, s in enumerate(sims)]
+    _attach_p2p(engs)
+    with pytest.raises(capi.FdtdError, match="timed out"):
+        engs[0].run(1)          # rank 1 is never stepped: rank 0's H half-step waits for an E halo that does not come

@@ -1,0 +1,28 @@
+"""Per-step cost of ONE interior z-slab of the NS grid whose halos travel to itself (FDTD_FLAG_LOOPBACK) through RCCL
+self send/recv or through peer copies (fdtd_link): kernel + launch + RCCL call overhead of the multi-GPU step loop, without the xGMI hop.
+world = 4 / 8 -> 15 / 7-8 planes per slab; split = overlapped schedule (default), nosplit = one launch per sweep."""
+import os, sys, time, importlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = "fdtd-solver-antennas_amd"
+capi = importlib.import_module(PKG + "._capi"); wl = importlib.import_module(PKG + ".workloads")
+sc = importlib.import_module(PKG + ".scene"); simm = importlib.import_module(PKG + ".simulation")
+hip = capi.load_hip_library()
+w = wl.baseline_workload(sys.argv[1] if len(sys.argv) > 1 else "NS"); vox = sc.voxelize(w.scene, w.grid)
+for world in (4, 8):
+    for name, fl in (("split", capi.FLAG_OVERLAP_ON), ("nosplit", capi.FLAG_OVERLAP_OFF)):
+        sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=10, nr_ts=5000, nf2ff_freqs=[w.f0])
+        for transport in ("rccl", "peer-copy"):
+            e = sim.build(hip, rank=1, world=world, flags=capi.FLAG_LOOPBACK | fl)
+            if transport == "rccl":
+                e.comm_init(capi.comm_unique_id(hip))
+                run = e.run
+            else:
+                capi.link(e, e)
+                run = lambda n, e=e: capi.run_linked([e], n)
+            run(200)
+            t0 = time.perf_counter(); run(2000); dt = time.perf_counter() - t0
+            cells = e.nk * e.ny * e.nx
+            print(f"world {world} rank 1 ({e.nk} planes, {cells/1e6:.2f} Mcells) {name} {transport}: {dt/2000*1e6:.1f} us per step "
+                  f"-> {world} such slabs = {w.grid.ncells*2000/dt/1e9:.1f} Gcells/s if the ranks ran alike", flush=True)
+            del e
+        del sim
