@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "fdtd_operator_form", "fdtd_get_operator", "fdtd_set_cpml",
     "fdtd_set_mur", "fdtd_set_signal", "fdtd_add_source", "fdtd_add_probe", "fdtd_get_probe",
     "fdtd_set_dft", "fdtd_add_dft_box", "fdtd_get_dft_box", "fdtd_run", "fdtd_run_profiled",
-    "fdtd_get_step", "fdtd_energy", "fdtd_p2p_export", "fdtd_p2p_attach", "fdtd_comm_unique_id", "fdtd_comm_init", "fdtd_link", "fdtd_run_linked", "fdtd_half_step",
+    "fdtd_get_step", "fdtd_energy", "fdtd_p2p_export", "fdtd_p2p_attach", "fdtd_p2p_selftest", "fdtd_p2p_detach", "fdtd_comm_unique_id", "fdtd_comm_init", "fdtd_link", "fdtd_run_linked", "fdtd_half_step",
     "fdtd_halo_get", "fdtd_halo_put", "fdtd_get_field", "fdtd_set_field", "fdtd_farfield",
 ]
 
@@ -80,6 +80,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
         "fdtd_energy": (C.c_int, [p, p]),
         "fdtd_p2p_export": (C.c_int, [p, p]),
         "fdtd_p2p_attach": (C.c_int, [p, p, p]),
+        "fdtd_p2p_selftest": (C.c_int, [p, C.c_uint]),
+        "fdtd_p2p_detach": (C.c_int, [p]),
         "fdtd_comm_unique_id": (C.c_int, [p]),
         "fdtd_comm_init": (C.c_int, [p, p]),
         "fdtd_link": (C.c_int, [p, p]),
@@ -360,6 +362,12 @@ class Engine:
         lo = C.create_string_buffer(lower, 128) if lower is not None else None
         hi = C.create_string_buffer(upper, 128) if upper is not None else None
         self._ck(self.lib.fdtd_p2p_attach(self._ctx, lo, hi), "p2p_attach")
+
+    def p2p_selftest(self, token: int = 0x5E1F0001):
+        self._ck(self.lib.fdtd_p2p_selftest(self._ctx, int(token)), "p2p_selftest")
+
+    def p2p_detach(self):
+        self._ck(self.lib.fdtd_p2p_detach(self._ctx), "p2p_detach")
 
     def comm_init(self, uid: bytes):
         if len(uid) != 128:

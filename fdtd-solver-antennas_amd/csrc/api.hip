@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "fdtd_ctx.h"
@@ -1034,6 +1035,8 @@ int fdtd_halo_put(fdtd_ctx* c, int which, const float* buf) {
 // ---- P2P mailbox transport ----------------------------------------------------------------------------------
 // Mailbox of a context: [E: 2 parities x 2 comps x plane][H: the same] floats, then 64 control words:
 // [0] E halos received, [1] H halos received, [2],[3] arrival counters, [4] error word, [8..] self-test slots.
+__global__ void k_wallclock(unsigned long long* out) { *out = (unsigned long long)wall_clock64(); }
+
 struct P2pBlob { hipIpcMemHandle_t h; uint64_t bytes; uint64_t raw; int32_t pid, device, nx, ny; };
 static_assert(sizeof(P2pBlob) <= 128, "blob must fit the 128-byte exchange buffer");
 
@@ -1045,6 +1048,7 @@ static int p2p_alloc(fdtd_ctx* c) {
   c->mbox_bytes = p2p_floats(c) * sizeof(float) + 64 * sizeof(unsigned);
   HIPCK(c, hipMalloc(&c->mbox, c->mbox_bytes));
   HIPCK(c, hipMemset(c->mbox, 0, c->mbox_bytes));
+  HIPCK(c, hipDeviceSynchronize());   // the kernels run on a non-blocking stream: the zeros must be there first
   return FDTD_OK;
 }
 
@@ -1103,7 +1107,83 @@ int fdtd_p2p_attach(fdtd_ctx* c, const void* lower128, const void* upper128) {
     waves += (rows * p.P4 + 63) / 64;
   }
   p.p2p_waves = waves;
+  // wall_clock64() tick rate: measured against the host clock (the attribute is not reliable on every part)
+  {
+    unsigned long long* d_t = nullptr;
+    HIPCK(c, hipMalloc(&d_t, 2 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_wallclock, dim3(1), dim3(1), 0, c->stream, d_t);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    const auto h0 = std::chrono::steady_clock::now();
+    usleep(20000);
+    hipLaunchKernelGGL(k_wallclock, dim3(1), dim3(1), 0, c->stream, d_t + 1);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
+    unsigned long long t[2];
+    HIPCK(c, hipMemcpy(t, d_t, sizeof(t), hipMemcpyDeviceToHost));
+    hipFree(d_t);
+    double hz = (double)(t[1] - t[0]) / dt;
+    if (getenv("FDTD_P2P_DEBUG")) fprintf(stderr, "[fdtd-hip] wall_clock64: %llu -> %llu in %.4f s = %.3e Hz\n", t[0], t[1], dt, hz);
+    if (!(hz > 1e6 && hz < 1e11)) hz = 1e8;
+    p.p2p_limit = (unsigned long long)(hz * 10.0);
+  }
   p.p2p = 1;
+  return FDTD_OK;
+}
+
+// Hand-shake over the attached mailboxes: every rank writes a token into its neighbours' control words and waits
+// (bounded, 10 s) for theirs — proves that the peer mappings are writable and that system-scope stores and polls
+// cross the link, before any timestep depends on it.  Call on all ranks at about the same time.
+__global__ void k_p2p_selftest(const DevParams p, const unsigned token, int* result) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned* mine = p.fl_in;
+  if (p.fl_out_E) __hip_atomic_store(p.fl_out_E + 8 + 1, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);        // lower's "from upper" slot
+  if (p.fl_out_H) __hip_atomic_store((p.fl_out_H - 1) + 8 + 0, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // upper's "from lower" slot
+  const unsigned long long t0 = wall_clock64();
+  int ok = 1;
+  for (int side = 0; side < 2; ++side) {
+    const bool have = side == 0 ? p.mb_in_H != nullptr : p.mb_in_E != nullptr;   // lower / upper neighbour exists
+    if (!have) continue;
+    while (__hip_atomic_load(mine + 8 + side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != token) {
+      __builtin_amdgcn_s_sleep(16);
+      if ((unsigned long long)wall_clock64() - t0 > p.p2p_limit) { ok = 0; break; }
+    }
+  }
+  *result = ok;
+}
+
+int fdtd_p2p_selftest(fdtd_ctx* c, unsigned token) {
+  if (!c) return FDTD_E_ARG;
+  if (!c->p.p2p) return fdtd_fail(c, FDTD_E_STATE, "p2p transport not attached");
+  HIPCK(c, hipSetDevice(c->d.device));
+  int* d_res = nullptr;
+  HIPCK(c, hipMalloc(&d_res, sizeof(int)));
+  HIPCK(c, hipMemsetAsync(d_res, 0, sizeof(int), c->stream));   // the context's stream is non-blocking: keep everything on it
+  hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(64), 0, c->stream, c->p, token, d_res);
+  int res = 0;
+  hipError_t e = hipMemcpyAsync(&res, d_res, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_res);
+  HIPCK(c, e);
+  if (!res) {
+    unsigned slots[2] = {0, 0};
+    hipMemcpy(slots, c->p.fl_in + 8, sizeof(slots), hipMemcpyDeviceToHost);
+    return fdtd_fail(c, FDTD_E_DEVICE, "p2p self-test: no token from a neighbour within the time limit (expected %#x; mailbox now holds from-lower %#x, from-upper %#x)",
+                     token, slots[0], slots[1]);
+  }
+  return FDTD_OK;
+}
+
+// Drop the mailbox transport again (e.g. to fall back to RCCL after a failed self-test).
+int fdtd_p2p_detach(fdtd_ctx* c) {
+  if (!c) return FDTD_E_ARG;
+  HIPCK(c, hipSetDevice(c->d.device));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  if (c->peer_lo && c->peer_lo_ipc) hipIpcCloseMemHandle(c->peer_lo);
+  if (c->peer_hi && c->peer_hi_ipc) hipIpcCloseMemHandle(c->peer_hi);
+  c->peer_lo = c->peer_hi = nullptr; c->peer_lo_ipc = c->peer_hi_ipc = false;
+  DevParams& p = c->p;
+  p.p2p = 0; p.mb_in_E = p.mb_in_H = p.mb_out_E = p.mb_out_H = nullptr; p.fl_out_E = p.fl_out_H = nullptr;
+  if (c->mbox) { HIPCK(c, hipMemset(c->mbox, 0, c->mbox_bytes)); HIPCK(c, hipDeviceSynchronize()); }
   return FDTD_OK;
 }
 

@@ -82,6 +82,7 @@ struct DevParams {
   unsigned* fl_out_E; unsigned* fl_out_H;   // &lower->fl_in[0], &upper->fl_in[1]
   unsigned* p2p_cnt;         // local arrival counters [2]
   int* p2p_err;              // set when a halo wait timed out
+  unsigned long long p2p_limit;   // wall-clock ticks a halo wait may last (10 s)
   int tys2, nbs2, nstrips2;
   int nt;                    // 1: non-temporal stores for the field outputs (working set beyond the Infinity Cache)  // tiling of the fused kernel (blocks of 4 x 63 owner groups)
   // fused soft sources (update_E) and probes (extra block of update_E / update_H)

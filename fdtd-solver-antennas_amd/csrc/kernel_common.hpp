@@ -55,35 +55,46 @@ __device__ __forceinline__ void decode_block_fd(const FastDiv& fd_ps, const Fast
   strip = (int)s; kk = (int)k; pb = (int)(rem - k * fd_nbs.d);
 }
 // ---- P2P mailbox protocol -------------------------------------------------------------------------------------------
-// system-scope loads (bypass this XCD's L2, which may hold the mailbox lines of two steps ago)
+// Mailbox words are only ever touched with system-scope (sc0 sc1) loads and stores, which go past this XCD's L2 to
+// memory / the fabric.  That is what lets the protocol do WITHOUT system-scope fences: a release or acquire fence
+// at system scope writes back or invalidates the whole L2 (measured: 300 us per step when every wave of the halo
+// plane issues one); here a wave only waits for its own write-through stores to be acknowledged (vmcnt) before it
+// counts itself in, and the flag is published by the wave that completes the count.
 __device__ __forceinline__ float4 ld4_sys(const float* q) {
   return make_float4(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
                      __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }
-// One lane per wave polls the flag until it reaches `need` (bounded: ~2 s of the 100 MHz wall clock, then the error
-// word is set and the wave goes on with whatever the mailbox holds); acquire at system scope afterwards.
-__device__ __forceinline__ void p2p_wait(const unsigned* flag, const unsigned need, int* err) {
+__device__ __forceinline__ void st4_sys(float* q, const float4& v) {
+  __hip_atomic_store(q, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(q + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(q + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(q + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// One lane per wave polls the flag until it reaches `need` (bounded: `limit` ticks of the wall clock = 10 s, then the
+// error word is set and the wave goes on with whatever the mailbox holds; once the error word is set no wait spins).  The mailbox loads that follow are issued after
+// the loop in program order and bypass the caches, so a workgroup-scope fence (no cache maintenance) is enough.
+__device__ __forceinline__ void p2p_wait(const unsigned* flag, const unsigned need, int* err, const unsigned long long limit) {
   const unsigned long long m = __ballot(1);
   if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
       __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > 200000000ull) { *err = 1; break; }
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+      if ((unsigned long long)wall_clock64() - t0 > limit) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
   }
-  __threadfence_system();   // acquire: nothing below may be satisfied from before the flag was seen
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-// After a wave has stored its part of a halo into the neighbour's mailbox: release at system scope, count the wave;
-// the wave that completes the plane publishes flag = value to the neighbour.
+// After a wave has stored its part of a halo into the neighbour's mailbox (st4_sys): wait for the acknowledgement of
+// those stores, count the wave; the wave that completes the plane publishes flag = value to the neighbour.
 __device__ __forceinline__ void p2p_arrive(unsigned* cnt, const unsigned total, unsigned* flag, const unsigned value) {
-  __threadfence_system();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): this wave's write-through stores are done
   const unsigned long long m = __ballot(1);
   if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
-    const unsigned old = atomicAdd(cnt, 1u);
+    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (old == total - 1u) {
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();
-      __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const
   if (COEF != 0 || (FUSE && p.nsrc > 0)) __syncthreads();
   if (!valid) return;
   if (dep_in) {   // H halo of step-1 (flag value = steps delivered); parity of the step that produced it
-    p2p_wait(p.fl_in + 1, (unsigned)step, p.p2p_err);
+    p2p_wait(p.fl_in + 1, (unsigned)step, p.p2p_err, p.p2p_limit);
     const float* mb = p.mb_in_H + (size_t)((step + 1) & 1) * 2 * p.plane + (j * p.P + i0);
     ix_km = ld4_sys(mb);
     iy_km = ld4_sys(mb + p.plane);
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const
   sto4s(p.nt, p.V[2], (unsigned)off, vz);
   if (P2P && k == 0 && p.mb_out_E != nullptr) {   // push the new Vx, Vy of the bottom plane into the lower rank's mailbox
     float* mb = p.mb_out_E + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
-    st4(mb, vx);
-    st4(mb + p.plane, vy);
+    st4_sys(mb, vx);
+    st4_sys(mb + p.plane, vy);
     p2p_arrive(p.p2p_cnt + 0, (unsigned)p.p2p_waves, p.fl_out_E, (unsigned)step + 1u);
   }
 }
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_H_MINBLOCKS) void k_update_H(const
   const float vz_ip = ldo1(p.V[2], uo + 4), vy_ip = ldo1(p.V[1], uo + 4);
   float4 ix = ldo4(p.I[0], uo), iy = ldo4(p.I[1], uo), iz = ldo4(p.I[2], uo);
   if (dep_in) {   // E halo of this step
-    p2p_wait(p.fl_in + 0, (unsigned)step + 1u, p.p2p_err);
+    p2p_wait(p.fl_in + 0, (unsigned)step + 1u, p.p2p_err, p.p2p_limit);
     const float* mb = p.mb_in_E + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
     vx_kp = ld4_sys(mb);
     vy_kp = ld4_sys(mb + p.plane);
@@ -281,8 +281,8 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_H_MINBLOCKS) void k_update_H(const
   sto4s(p.nt, p.I[2], uo, iz);
   if (P2P && k == p.nk - 1 && p.mb_out_H != nullptr) {   // push the new Ix, Iy of the top plane into the upper rank's mailbox
     float* mb = p.mb_out_H + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
-    st4(mb, ix);
-    st4(mb + p.plane, iy);
+    st4_sys(mb, ix);
+    st4_sys(mb + p.plane, iy);
     p2p_arrive(p.p2p_cnt + 1, (unsigned)p.p2p_waves, p.fl_out_H, (unsigned)step + 1u);
   }
 }

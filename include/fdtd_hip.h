@@ -208,6 +208,10 @@ int fdtd_comm_init(fdtd_ctx* ctx, const void* uid128);
  *      every rank attaches its neighbours' blobs (null where there is none).  Needs >= 2 planes per slab, no Mur. */
 int fdtd_p2p_export(fdtd_ctx* ctx, void* out128);
 int fdtd_p2p_attach(fdtd_ctx* ctx, const void* lower128, const void* upper128);
+/* Hand-shake with the attached neighbours (token written into their mailboxes, theirs awaited for <= 10 s): call on
+ * all ranks at about the same time, before the first step.  Error = fall back (fdtd_p2p_detach, then e.g. RCCL). */
+int fdtd_p2p_selftest(fdtd_ctx* ctx, unsigned token);
+int fdtd_p2p_detach(fdtd_ctx* ctx);
 /* (a') Several slabs inside ONE process (one host thread driving several GPUs, or several slabs on one GPU):
  *      link adjacent contexts, then step them together; halos move by peer copies on the communication
  *      streams with the same overlapped schedule as the RCCL path. ctxs[r] must be rank r of a world of n. */

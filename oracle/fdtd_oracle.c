@@ -727,6 +727,8 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
 
 int fdtd_p2p_export(fdtd_ctx* c, void* out128) { (void)out128; return fail(c, FDTD_E_UNSUPPORTED, "oracle has no device transport"); }
 int fdtd_p2p_attach(fdtd_ctx* c, const void* lo, const void* hi) { (void)lo; (void)hi; return fail(c, FDTD_E_UNSUPPORTED, "oracle has no device transport"); }
+int fdtd_p2p_selftest(fdtd_ctx* c, unsigned token) { (void)token; return fail(c, FDTD_E_UNSUPPORTED, "oracle has no device transport"); }
+int fdtd_p2p_detach(fdtd_ctx* c) { return c ? FDTD_OK : FDTD_E_ARG; }
 int fdtd_comm_unique_id(void* out128) { (void)out128; return fail(NULL, FDTD_E_UNSUPPORTED, "oracle has no RCCL transport"); }
 int fdtd_comm_init(fdtd_ctx* c, const void* uid) { (void)uid; return fail(c, FDTD_E_UNSUPPORTED, "oracle has no RCCL transport"); }
 

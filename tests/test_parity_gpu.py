@@ -354,7 +354,7 @@ def test_p2p_mailbox_transport_slabs_equal_one_slab(hip_lib, world):
 
 
 def test_p2p_wait_times_out_instead_of_hanging(hip_lib):
-    """A rank whose neighbour never steps: the bounded halo wait gives up after ~2 s and fdtd_run reports it."""
+    """A rank whose neighbour never steps: the bounded halo wait gives up (10 s) and fdtd_run reports it."""
     capi = pkg("_capi")
     sims = [patch_sim(40, 36, 24, nr_ts=20, nf2ff=False) for _ in range(2)]
     engs = [s.build(hip_lib, rank=r, world=2) for r, s in enumerate(sims)]

@@ -11,9 +11,18 @@ w = wl.baseline_workload(sys.argv[1] if len(sys.argv) > 1 else "NS"); vox = sc.v
 for world in (4, 8):
     for name, fl in (("split", capi.FLAG_OVERLAP_ON), ("nosplit", capi.FLAG_OVERLAP_OFF)):
         sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=10, nr_ts=5000, nf2ff_freqs=[w.f0])
-        for transport in ("rccl", "peer-copy"):
+        for transport in ("rccl", "peer-copy", "p2p-mailbox"):
             e = sim.build(hip, rank=1, world=world, flags=capi.FLAG_LOOPBACK | fl)
-            if transport == "rccl":
+            if transport == "p2p-mailbox":
+                if name == "nosplit":
+                    del e
+                    continue
+                del e
+                e = sim.build(hip, rank=1, world=world)
+                blob = e.p2p_export()
+                e.p2p_attach(blob, blob)       # both neighbours = this slab itself
+                run = e.run
+            elif transport == "rccl":
                 e.comm_init(capi.comm_unique_id(hip))
                 run = e.run
             else:
