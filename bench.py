@@ -8,7 +8,8 @@ CPML, source, port probes and NF2FF running-DFT surfaces) of the named BASELINE 
 workload is the north-star 300x300x60 patch-on-FR-4 grid with 10-cell CPML, fp32.  Inputs are
 resident in HBM before the timed region.  For N > 1 (launched by torch.distributed.run, one rank
 per GPU) the SAME global grid is z-slab decomposed over the ranks (strong scaling, as BASELINE.json
-states the target) with RCCL halo exchange inside libfdtd_hip.so.
+states the target); the halo planes travel inside libfdtd_hip.so — P2P mailboxes written by the update
+kernels over xGMI by default, RCCL send/recv on a second stream with `--halo rccl`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event kernel
 durations of the dominant kernel vs 36 algorithmic bytes per cell per half-step) and, at N = 1,
@@ -42,6 +43,8 @@ def main():
     ap.add_argument("--ts-per-step", type=int, default=100)
     ap.add_argument("--cpml-cells", type=int, default=10)
     ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "fused", "tile", "march"])
+    ap.add_argument("--halo", default="auto", choices=["auto", "p2p", "rccl", "host"],
+                    help="N > 1: halo transport (auto = P2P mailbox, then RCCL, then host copies)")
     ap.add_argument("--raw-operator", action="store_true", help="stream 12 coefficient arrays instead of class bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle timesteps for the cpu_baseline leg (0 = auto)")
@@ -83,9 +86,10 @@ def main():
     eng = sim.build(hip, rank=rank, world=world, device=local_rank, flags=flags)
     comm = None
     if world > 1:
-        # RCCL halo exchange inside the library; if the communicator cannot be created on this node every
-        # rank falls back (together) to the host transport so that the run still produces a valid number
-        comm = importlib.import_module(PKG + ".distributed").SlabComm(transport="auto")
+        # halo transport inside the library: P2P mailboxes (kernels push the halo planes over xGMI), else RCCL
+        # send/recv on a second stream; if neither can be set up on this node every rank falls back (together) to
+        # the host transport so that the run still produces a valid number
+        comm = importlib.import_module(PKG + ".distributed").SlabComm(transport=args.halo)
         comm.attach(sim)
 
     def run_steps(n):
