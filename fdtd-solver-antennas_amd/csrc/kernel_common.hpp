@@ -60,15 +60,18 @@ __device__ __forceinline__ void decode_block_fd(const FastDiv& fd_ps, const Fast
 // at system scope writes back or invalidates the whole L2 (measured: 300 us per step when every wave of the halo
 // plane issues one); here a wave only waits for its own write-through stores to be acknowledged (vmcnt) before it
 // counts itself in, and the flag is published by the wave that completes the count.
+// 128-bit accesses with the system-coherence bits (sc0 sc1) set: one fabric request per lane instead of four 4-byte
+// ones (over xGMI every request is a packet).  The compiler has no builtin for a 16-byte system-scope access, so
+// the two instructions are spelled out; the load waits for its own data (nothing else is in flight at that point).
+typedef float v4f_sys __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld4_sys(const float* q) {
-  return make_float4(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
-                     __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  v4f_sys r;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(q) : "memory");
+  return make_float4(r.x, r.y, r.z, r.w);
 }
 __device__ __forceinline__ void st4_sys(float* q, const float4& v) {
-  __hip_atomic_store(q, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(q + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(q + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(q + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const v4f_sys t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(q), "v"(t) : "memory");
 }
 // One lane per wave polls the flag until it reaches `need` (bounded: `limit` ticks of the wall clock = 10 s, then the
 // error word is set and the wave goes on with whatever the mailbox holds; once the error word is set no wait spins).  The mailbox loads that follow are issued after
@@ -88,7 +91,8 @@ __device__ __forceinline__ void p2p_wait(const unsigned* flag, const unsigned ne
 // After a wave has stored its part of a halo into the neighbour's mailbox (st4_sys): wait for the acknowledgement of
 // those stores, count the wave; the wave that completes the plane publishes flag = value to the neighbour.
 __device__ __forceinline__ void p2p_arrive(unsigned* cnt, const unsigned total, unsigned* flag, const unsigned value) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): this wave's write-through stores are done
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's write-through mailbox stores are acknowledged
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   const unsigned long long m = __ballot(1);
   if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
     const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
