@@ -973,6 +973,7 @@ int fdtd_energy(fdtd_ctx* c, double sums[2]) {
 int fdtd_half_step(fdtd_ctx* c, int phase) {
   int r = check_ready(c);
   if (r) return r;
+  if (c->p.p2p) return fdtd_fail(c, FDTD_E_STATE, "fdtd_half_step drives an external halo transport; detach the p2p transport first");
   HIPCK(c, hipSetDevice(c->d.device));
   hipStream_t s = c->stream;
   if (phase == FDTD_PHASE_E) {
@@ -1289,6 +1290,7 @@ int fdtd_comm_unique_id(void* out128) {
 int fdtd_comm_init(fdtd_ctx* c, const void* uid128) {
   if (!c || !uid128) return fdtd_fail(c, FDTD_E_ARG, "null argument");
   if (c->comm) return fdtd_fail(c, FDTD_E_STATE, "communicator already initialised");
+  if (c->p.p2p) return fdtd_fail(c, FDTD_E_STATE, "the p2p transport is attached; detach it before creating an RCCL communicator");
   HIPCK(c, hipSetDevice(c->d.device));
   ncclUniqueId id;
   memcpy(&id, uid128, 128);
