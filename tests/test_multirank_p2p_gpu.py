@@ -31,10 +31,16 @@ def _worker(rank, world, port, out_dir):
     comm = pkg("distributed").SlabComm(transport="p2p")
     comm.attach(s)
     assert comm.transport_used == "p2p" and s.external_transport is None
-    for n in (1, 60, STEPS - 61):
-        e.run(n)
+    if world == 2:      # the host-level driver: chunks of 40 steps with the all-reduced energy criterion in between
+        st = s.run(check_every=40, allreduce=comm.allreduce)
+        assert st.steps == STEPS
+    else:
+        for n in (1, 60, STEPS - 61):
+            e.run(n)
     u, i = s.port_series(comm.allreduce)[0]
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), fields=e.fields(), u=u, i=i, k0=e.k0, nk=e.nk, step=e.step)
+    boxes = s.nf2ff_boxes(comm.allreduce)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), fields=e.fields(), u=u, i=i, k0=e.k0, nk=e.nk, step=e.step,
+             **{f"box{n}": b for n, b in enumerate(boxes)})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,3 +63,5 @@ def test_p2p_ranks_in_separate_processes_equal_one_slab(hip_lib, tmp_path, world
     assert np.array_equal(both.view(np.uint32), ref.view(np.uint32))
     u, i = s.port_series()[0]
     assert np.allclose(r[0]["u"], u, rtol=1e-12, atol=0) and np.allclose(r[-1]["i"], i, rtol=1e-12, atol=1e-300)
+    for n, b in enumerate(s.nf2ff_boxes()):      # rank-summed running-DFT surfaces == single-slab surfaces
+        assert np.allclose(r[0][f"box{n}"], b, rtol=1e-12, atol=1e-30) and np.allclose(r[-1][f"box{n}"], b, rtol=1e-12, atol=1e-30)
