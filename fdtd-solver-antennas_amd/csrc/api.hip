@@ -637,6 +637,26 @@ static int exchange(fdtd_ctx* c, int which) {
   return FDTD_OK;
 }
 
+// Soft sources may stay inside update_E (and the probes in the extra blocks of the main kernels) also in a scene with
+// Mur faces, as long as no source edge sits on a Mur face or on the plane next to it: the Mur "post" pass reads the
+// freshly updated voltages of that inner plane BEFORE the sources are added in the unfused order, so only there the
+// order of the two matters.  (The reference's ports sit in the middle of the box.)  Saves two launches per step.
+static bool sources_fusable(const fdtd_ctx* c) {
+  if (!c->any_mur) return true;
+  const int n[3] = {c->d.nx, c->d.ny, c->d.nz};
+  for (int off : c->h_src_off) {
+    const int k = off / c->plane, j = (off - k * c->plane) / c->P, i = off - k * c->plane - j * c->P;
+    const int pos[3] = {i, j, c->d.k0 + k};
+    for (int f = 0; f < 6; ++f) {
+      const int a = f / 2;
+      const bool enabled = a == 2 ? true : c->mur[f].on != 0;   // a z face may live on another rank: be conservative
+      if (!enabled) continue;
+      if ((f & 1) ? pos[a] >= n[a] - 2 : pos[a] <= 1) return false;
+    }
+  }
+  return true;
+}
+
 static bool fused_eligible(const fdtd_ctx* c) {
   return c->d.world == 1 && !c->any_mur && c->have_op && !c->raw_op;
 }
@@ -758,11 +778,9 @@ static int phase_E(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
     if (r) return r;
     launch_update_E(c, 0, 1, step, fused, false, s);
   }
-  if (!fused) {
-    launch_mur(c, 1, s);
-    launch_mur(c, 2, s);
-    launch_post(c, FDTD_KIND_V, step, true, s);
-  }
+  launch_mur(c, 1, s);   // post + apply (no-ops without Mur faces)
+  launch_mur(c, 2, s);
+  if (!fused) launch_post(c, FDTD_KIND_V, step, true, s);
   launch_dft(c, FDTD_KIND_V, step, s);
   if (multi) HIPCK(c, hipEventRecord(c->ev_E, s));
   return FDTD_OK;
@@ -813,7 +831,7 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   if (c->p.p2p) return step_loop_p2p(c, nsteps, pe);
   const bool multi = c->d.world > 1;
   if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_p2p_attach (mailbox transport), fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
-  const bool fused = !c->any_mur;
+  const bool fused = sources_fusable(c);
   for (int n = 0; n < nsteps; ++n) {
     int r = phase_E(c, multi, fused, pe, n);
     if (r) return r;
@@ -1256,16 +1274,16 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
   }
   for (int s = 0; s < nsteps; ++s) {
     int rc;
-    for (int r = 0; r < n; ++r) if ((rc = phase_E(ctxs[r], multi, !ctxs[r]->any_mur, nullptr, 0))) return rc;
+    for (int r = 0; r < n; ++r) if ((rc = phase_E(ctxs[r], multi, sources_fusable(ctxs[r]), nullptr, 0))) return rc;
     if (multi) for (int r = 0; r < n; ++r) { if ((rc = exchange(ctxs[r], FDTD_HALO_E_DOWN))) return rc; ctxs[r]->haloE_issued = true; }
-    for (int r = 0; r < n; ++r) if ((rc = phase_H(ctxs[r], multi, !ctxs[r]->any_mur, nullptr, 0))) return rc;
+    for (int r = 0; r < n; ++r) if ((rc = phase_H(ctxs[r], multi, sources_fusable(ctxs[r]), nullptr, 0))) return rc;
     if (multi) for (int r = 0; r < n; ++r) { if ((rc = exchange(ctxs[r], FDTD_HALO_H_UP))) return rc; ctxs[r]->haloH_issued = true; }
     for (int r = 0; r < n; ++r) ctxs[r]->step++;
   }
   for (int r = 0; r < n; ++r) {
     fdtd_ctx* c = ctxs[r];
     HIPCK(c, hipSetDevice(c->d.device));
-    if (!c->any_mur && nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);
+    if (sources_fusable(c) && nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);
     HIPCK(c, hipGetLastError());
   }
   for (int r = 0; r < n; ++r) {
