@@ -208,8 +208,15 @@ class LumpedPort:
         tu = np.arange(u.size) * dt
         ti = (np.arange(i.size) + 0.5) * dt
         self.u_data, self.i_data = UIData(tu, u), UIData(ti, i)
-        self.uf_tot = dft_time2freq(tu, u, self.freq, signal_type)
-        self.if_tot = dft_time2freq(ti, i, self.freq, signal_type)
+        if u.size == i.size and u.size > 1:
+            # one exponent matrix for both series: exp(-jw(t + dt/2)) = exp(-jwt) * exp(-jw dt/2)
+            ex = np.exp(-2j * np.pi * np.outer(self.freq, tu))
+            scale = 2.0 * (dt if signal_type == "pulse" else 1.0 / u.size)
+            self.uf_tot = (ex @ np.asarray(u, float)) * scale
+            self.if_tot = (ex @ np.asarray(i, float)) * np.exp(-1j * np.pi * self.freq * dt) * scale
+        else:
+            self.uf_tot = dft_time2freq(tu, u, self.freq, signal_type)
+            self.if_tot = dft_time2freq(ti, i, self.freq, signal_type)
         self.uf_inc = 0.5 * (self.uf_tot + self.if_tot * self.Z_ref)
         self.if_inc = 0.5 * (self.if_tot + self.uf_tot / self.Z_ref)
         self.uf_ref = self.uf_tot - self.uf_inc
