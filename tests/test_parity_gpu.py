@@ -361,3 +361,42 @@ def test_p2p_wait_times_out_instead_of_hanging(hip_lib):
     _attach_p2p(engs)
     with pytest.raises(capi.FdtdError, match="timed out"):
         engs[0].run(1)          # rank 1 is never stepped: rank 0's H half-step waits for an E halo that does not come
+
+
+@pytest.mark.parametrize("src_i", [1, 9])
+def test_mur_with_sources_next_to_and_away_from_a_face(hip_lib, oracle_lib, src_i):
+    """Mur scene driven through the C ABI directly: a source edge ON the plane next to the x- Mur face (src_i = 1: the
+    order 'Mur post, then source' matters, so the library must take the unfused launch sequence) and in the interior
+    (src_i = 9: sources/probes stay fused in the main kernels) — both identical to the oracle, fields and probe series."""
+    capi, const = pkg("_capi"), pkg("constants")
+    from opbuild_cases import random_scene
+    grid, eps, kap, pec, _ = random_scene(21, (22, 20, 18), False, 3, n_lumped=0, pec_frac=0.0)
+    dt = grid.courant_dt()
+    nx, ny, nz = grid.shape
+    n = 160
+    out = []
+    for lib in (hip_lib, oracle_lib):
+        e = capi.Engine(lib, nx, ny, nz, dt, max_steps=n + 8)
+        eco = pkg("ecoperator")
+        emet, hmet = eco.pack_metric_tables(*eco.metric_lists(grid, dt), grid)
+        e.build_operator(grid.d, eps, kap, pec, const.EPS0, eco.lumped_overrides(grid, eps, kap, pec, dt, []), emet, hmet)
+        coeff = []
+        for f in range(6):
+            l = grid.lines[f // 2]
+            d = (l[-1] - l[-2]) if f % 2 else (l[1] - l[0])
+            coeff.append((const.C0 * dt - d) / (const.C0 * dt + d))
+        e.set_mur([1] * 6, coeff)
+        t = np.arange(n) * dt
+        e.set_signal(np.sin(2 * np.pi * 8e9 * t) * np.exp(-((t - 40 * dt) / (15 * dt)) ** 2))
+        j, k = ny // 2, nz // 2
+        src = np.array([(k * ny + j) * nx + src_i, (k * ny + j + 1) * nx + src_i], np.int64)
+        e.add_source(src, np.array([2, 2], np.int8), np.array([1.0, -0.5], np.float32))
+        pv = e.add_probe(capi.KIND_V, np.array([(k * ny + j) * nx + src_i + 3], np.int64), np.array([2], np.int8), np.array([-1.0], np.float32))
+        pi = e.add_probe(capi.KIND_I, np.array([(k * ny + j) * nx + src_i + 3], np.int64), np.array([1], np.int8), np.array([1.0], np.float32))
+        for m in (1, 70, n - 71):
+            e.run(m)
+        out.append((e.fields(), e.get_probe(pv), e.get_probe(pi)))
+    (fh, uh, ih), (fo, uo, io) = out
+    assert np.abs(fo).max() > 0 and len(uo) == n
+    assert same_values(fh, fo), f"rel L2 {rel_l2(fh, fo):.3e}"
+    assert rel_l2(uh, uo) < 1e-12 and rel_l2(ih, io) < 1e-12
