@@ -1065,7 +1065,17 @@ static int p2p_alloc(fdtd_ctx* c) {
   if (c->mbox) return FDTD_OK;
   HIPCK(c, hipSetDevice(c->d.device));
   c->mbox_bytes = p2p_floats(c) * sizeof(float) + 64 * sizeof(unsigned);
-  HIPCK(c, hipMalloc(&c->mbox, c->mbox_bytes));
+  // Fine-grained (system-coherent) device memory: another GPU writes it while this GPU's kernels poll and read it, so
+  // it must never sit stale in this GPU's L2 (coarse-grained memory is only coherent at kernel boundaries).
+  if (getenv("FDTD_P2P_COARSE") || hipExtMallocWithFlags(&c->mbox, c->mbox_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    c->mbox = nullptr;
+    HIPCK(c, hipMalloc(&c->mbox, c->mbox_bytes));
+    c->mbox_fine = false;
+  } else {
+    c->mbox_fine = true;
+  }
+  if (getenv("FDTD_P2P_DEBUG")) fprintf(stderr, "[fdtd-hip] rank %d mailbox: %zu bytes, %s device memory\n", c->d.rank, c->mbox_bytes, c->mbox_fine ? "fine-grained" : "coarse-grained");
   HIPCK(c, hipMemset(c->mbox, 0, c->mbox_bytes));
   HIPCK(c, hipDeviceSynchronize());   // the kernels run on a non-blocking stream: the zeros must be there first
   return FDTD_OK;

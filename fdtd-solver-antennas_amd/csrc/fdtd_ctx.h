@@ -111,6 +111,7 @@ struct fdtd_ctx {
   int2* src_rng4 = nullptr; int* src_ids4 = nullptr;
   // P2P mailbox transport
   void* mbox = nullptr; size_t mbox_bytes = 0;     // my mailbox allocation
+  bool mbox_fine = false;                          // fine-grained (system-coherent) device memory
   void* peer_lo = nullptr; void* peer_hi = nullptr; // neighbours' mailboxes (IPC mappings or in-process pointers)
   bool peer_lo_ipc = false, peer_hi_ipc = false;
   int occ_e = 0, occ_h = 0;      // cap on resident blocks per CU of update_E / update_H (0: none); $FDTD_OCC_E / $FDTD_OCC_H
