@@ -54,6 +54,8 @@ class SlabComm:
         return t.cpu().numpy().reshape(a.shape)
 
     def barrier(self):
+        """Also the tear-down rule of the p2p transport: every rank must have finished its last run before any rank
+        frees its engine (a neighbour's last H half-step still writes into this rank's mailbox)."""
         self.dist.barrier()
 
     # -- transport selection ---------------------------------------------------------------------------

@@ -205,7 +205,9 @@ int fdtd_comm_init(fdtd_ctx* ctx, const void* uid128);
  *      on MI355X, an 8-plane slab of the north-star grid steps in ~80 us with grouped ncclSend/ncclRecv (or peer copies)
  *      ordered by events on a second stream, however small the slab — the reason for this transport.
  *      Every rank exports a 128-byte blob, the host program ships the blobs (e.g. torch.distributed all_gather),
- *      every rank attaches its neighbours' blobs (null where there is none).  Needs >= 2 planes per slab, no Mur. */
+ *      every rank attaches its neighbours' blobs (null where there is none).  Needs >= 2 planes per slab, no Mur.
+ *      Tear-down: a rank's last H half-step still writes into its upper neighbour's mailbox, so synchronise the ranks
+ *      (a barrier after the last fdtd_run) before any of them calls fdtd_p2p_detach or fdtd_destroy. */
 int fdtd_p2p_export(fdtd_ctx* ctx, void* out128);
 int fdtd_p2p_attach(fdtd_ctx* ctx, const void* lower128, const void* upper128);
 /* Hand-shake with the attached neighbours (token written into their mailboxes, theirs awaited for <= 10 s): call on
