@@ -189,6 +189,7 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
     const int v = (int)strtol(ts, nullptr, 16);
     if (v == 0x88 || v == 0x48 || v == 0x84 || v == 0x44) c->tile_shape = v;
   }
+  p.sweep_rev = getenv("FDTD_NO_SWEEP_REV") ? 0 : 1;
   if (const char* v = getenv("FDTD_OCC_E")) c->occ_e = std::max(0, std::min(16, atoi(v)));
   if (const char* v = getenv("FDTD_OCC_H")) c->occ_h = std::max(0, std::min(16, atoi(v)));
   if (const char* kc = getenv("FDTD_MARCH_KC")) {

@@ -71,6 +71,7 @@ struct DevParams {
   // launch tiling: a block = 256 threads = 1024 consecutive x-cells of one strip of `tys` rows in one plane
   int tys, nbs, nstrips;
   FastDiv fd_nbs, fd_P4;     // dividers for the block / thread decode
+  int sweep_rev;             // 1: update_H walks the blocks backwards (cache-friendly alternation with update_E)
   // P2P mailbox halo transport (in-kernel pushes over xGMI / peer mappings; no streams, events or RCCL in the step loop).
   // Mailbox layout (one allocation per context, zero at start): [E: 2 parities][2 comps][plane] floats, then the same
   // for H, then flags.  mb_in_*: my own mailbox; mb_out_*: the neighbour's (peer pointer), null without that neighbour.

@@ -45,9 +45,14 @@ __device__ __forceinline__ void decode_block(int nbs, int nkr, int extra, int& s
 }
 __device__ __forceinline__ unsigned fd_div(const unsigned n, const FastDiv& f) { return f.d == 1u ? n : __umulhi(n, f.mul) >> f.shr; }
 // the same decode with the three divisions replaced by multiply-high (two-pass kernels)
-__device__ __forceinline__ void decode_block_fd(const FastDiv& fd_ps, const FastDiv& fd_nbs, int extra, int& strip, int& kk, int& pb) {
+// rev: this XCD walks its range backwards.  update_E sweeps forwards and update_H backwards, so each half-step starts
+// on the data the previous one touched last (still in this XCD's L2 / the Infinity Cache) instead of on the data it
+// touched first (evicted by then on grids larger than the caches).
+__device__ __forceinline__ void decode_block_fd(const FastDiv& fd_ps, const FastDiv& fd_nbs, int extra, int rev, int& strip, int& kk, int& pb) {
   const unsigned nb = gridDim.x - (unsigned)extra, b = blockIdx.x;
-  const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
+  const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u;
+  unsigned pos = b >> 3;
+  if (rev) pos = (xcd < r ? q : q - 1u) - pos;
   const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
   const unsigned s = fd_div(v, fd_ps);
   const unsigned rem = v - s * fd_ps.d;

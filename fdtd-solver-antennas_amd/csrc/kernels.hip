@@ -46,7 +46,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const
   if (P2P) {   // all planes in one launch, the halo-dependent bottom plane last
     decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, 0, 1, strip, k, pb);
   } else {
-    decode_block_fd(fd_ps, p.fd_nbs, extra, strip, kk, pb);
+    decode_block_fd(fd_ps, p.fd_nbs, extra, 0, strip, kk, pb);
     k = k_begin + kk;
   }
   // coefficient table -> registers now, -> LDS after the field loads have been issued (loads return in order, so
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_H_MINBLOCKS) void k_update_H(const
   if (P2P) {   // all planes in one launch, the halo-dependent top plane last
     decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, p.nk - 1, 0, strip, k, pb);
   } else {
-    decode_block_fd(fd_ps, p.fd_nbs, extra, strip, kk, pb);
+    decode_block_fd(fd_ps, p.fd_nbs, extra, p.sweep_rev, strip, kk, pb);
     k = k_begin + kk;
   }
   if (!decode_thread(p, strip, pb, j, i0)) return;
