@@ -416,6 +416,7 @@ void choose_tiling(fdtd_ctx* c) {
     const double cost = idle + halo;
     if (cost < best_cost - 1e-12) { best_cost = cost; best = tys < ny ? tys : ny; }
   }
+  if (const char* e = getenv("FDTD_TYS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) best = v < ny ? v : ny; }   // experiments
   c->p.tys = best;
   c->p.nbs = (best * P4 + FDTD_BLOCK - 1) / FDTD_BLOCK;
   c->p.nstrips = (ny + best - 1) / best;
