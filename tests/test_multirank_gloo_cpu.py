@@ -26,9 +26,9 @@ def _worker(rank, world, port, out_dir):
     lib = pkg("_capi").bind(ctypes.CDLL(os.path.join(ROOT, "oracle", "libfdtd_oracle.so")))
     s = patch_sim(*SHAPE, cpml_cells=8, nr_ts=STEPS)
     e = s.build(lib, rank=rank, world=world)
-    comm = pkg("distributed").SlabComm(transport="host")
+    comm = pkg("distributed").SlabComm(transport="auto")     # CPU engine: p2p and rccl are not eligible -> all ranks agree on "host"
     comm.attach(s)
-    assert s.external_transport is comm
+    assert s.external_transport is comm and comm.transport_used == "host"
     st = s.run(check_every=40, allreduce=comm.allreduce)
     u, i = s.port_series(comm.allreduce)[0]
     boxes = s.nf2ff_boxes(comm.allreduce)
