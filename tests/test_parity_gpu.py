@@ -400,3 +400,38 @@ def test_mur_with_sources_next_to_and_away_from_a_face(hip_lib, oracle_lib, src_
     assert np.abs(fo).max() > 0 and len(uo) == n
     assert same_values(fh, fo), f"rel L2 {rel_l2(fh, fo):.3e}"
     assert rel_l2(uh, uo) < 1e-12 and rel_l2(ih, io) < 1e-12
+
+
+def test_largest_baseline_grid_two_p2p_slabs_equal_one(hip_lib):
+    """BASELINE's largest configuration (C5: 800x800x120, 2x2 array, four lumped ports, 76.8 Mcells) at full size:
+    two z-slabs coupled by the P2P mailbox transport reproduce the single-slab run bit for bit — exercises the index
+    arithmetic, the source lists and the mailboxes at the sizes the 8-GPU configuration is quoted on."""
+    capi, sim_m, wl, sc = pkg("_capi"), pkg("simulation"), pkg("workloads"), pkg("scene")
+    w = wl.baseline_workload("C5")
+    vox = sc.voxelize(w.scene, w.grid)
+    steps = 36
+
+    def make():
+        return sim_m.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=10, nr_ts=steps + 4, nf2ff_freqs=None)
+
+    s1 = make()
+    e1 = s1.build(hip_lib)
+    e1.run(steps)
+    ref = [e1.get_field(kind, comp) for kind in (0, 1) for comp in range(3)]
+    u1 = [np.asarray(s1.port_series()[q][0]) for q in range(len(vox.ports))]
+    del e1, s1
+    sims = [make(), make()]
+    engs = [s.build(hip_lib, rank=r, world=2) for r, s in enumerate(sims)]
+    _attach_p2p(engs)
+    capi.run_linked(engs, steps)
+    n = 0
+    for kind in (0, 1):
+        for comp in range(3):
+            both = np.concatenate([e.get_field(kind, comp) for e in engs], axis=0)
+            assert both.shape == ref[n].shape
+            assert np.array_equal(both.view(np.uint32), ref[n].view(np.uint32)), (kind, comp)
+            n += 1
+    assert max(np.abs(r).max() for r in ref) > 0
+    for q in range(len(vox.ports)):
+        u2 = sum(np.asarray(s.port_series()[q][0]) for s in sims)
+        assert rel_l2(u2, u1[q]) < 1e-12
