@@ -435,3 +435,23 @@ def test_largest_baseline_grid_two_p2p_slabs_equal_one(hip_lib):
     for q in range(len(vox.ports)):
         u2 = sum(np.asarray(s.port_series()[q][0]) for s in sims)
         assert rel_l2(u2, u1[q]) < 1e-12
+
+
+def test_c4_full_size_gpu_equals_oracle(hip_lib, oracle_lib):
+    """BASELINE config 4 at full size (512x512x128, 5.8 GHz microstrip-3D geometry, CPML-10): 40 timesteps on the HIP
+    library and on the oracle, every field value identical."""
+    sim_m, wl, sc = pkg("simulation"), pkg("workloads"), pkg("scene")
+    w = wl.baseline_workload("C4")
+    vox = sc.voxelize(w.scene, w.grid)
+    out = []
+    for lib in (hip_lib, oracle_lib):
+        s = sim_m.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=10, nr_ts=48, nf2ff_freqs=None)
+        e = s.build(lib)
+        e.run(40)
+        out.append(([e.get_field(kind, comp) for kind in (0, 1) for comp in range(3)], np.asarray(s.port_series()[0][0])))
+        del e, s
+    (fh, uh), (fo, uo) = out
+    assert max(np.abs(a).max() for a in fo) > 0
+    for a, b in zip(fh, fo):
+        assert same_values(a, b)
+    assert rel_l2(uh, uo) < 1e-12
