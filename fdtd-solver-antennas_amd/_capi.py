@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "fdtd_last_error", "fdtd_set_operator_raw", "fdtd_set_operator_classes", "fdtd_build_operator",
     "fdtd_operator_form", "fdtd_get_operator", "fdtd_set_cpml",
     "fdtd_set_mur", "fdtd_set_signal", "fdtd_add_source", "fdtd_add_probe", "fdtd_get_probe",
-    "fdtd_set_dft", "fdtd_add_dft_box", "fdtd_get_dft_box", "fdtd_run", "fdtd_run_profiled",
+    "fdtd_set_dft", "fdtd_add_dft_box", "fdtd_get_dft_box", "fdtd_set_recorder", "fdtd_rec_transform", "fdtd_run", "fdtd_run_profiled",
     "fdtd_get_step", "fdtd_energy", "fdtd_p2p_export", "fdtd_p2p_attach", "fdtd_p2p_selftest", "fdtd_p2p_detach", "fdtd_comm_unique_id", "fdtd_comm_init", "fdtd_link", "fdtd_run_linked", "fdtd_half_step",
     "fdtd_halo_get", "fdtd_halo_put", "fdtd_get_field", "fdtd_set_field", "fdtd_farfield",
 ]
@@ -74,6 +74,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
         "fdtd_set_dft": (C.c_int, [p, C.c_int, C.c_int, C.c_int, p, p]),
         "fdtd_add_dft_box": (C.c_int, [p, C.c_int, C.c_int, p, p, C.POINTER(C.c_int)]),
         "fdtd_get_dft_box": (C.c_int, [p, C.c_int, p, p, p]),
+        "fdtd_set_recorder": (C.c_int, [p, C.c_int, C.c_int]),
+        "fdtd_rec_transform": (C.c_int, [p, C.c_int, C.c_int, p, p, p, p]),
         "fdtd_run": (C.c_int, [p, C.c_int]),
         "fdtd_run_profiled": (C.c_int, [p, C.c_int, C.POINTER(FdtdProfile)]),
         "fdtd_get_step": (C.c_int, [p, C.POINTER(C.c_int64)]),
@@ -297,6 +299,29 @@ class Engine:
         self.nfreq = tw_v.shape[1]
         self._ck(self.lib.fdtd_set_dft(self._ctx, tw_v.shape[1], int(every), tw_v.shape[0], _ptr(tw_v), _ptr(tw_i)),
                  "set_dft")
+
+    def set_recorder(self, every: int, nsamples: int):
+        """Boxes keep their time-domain samples (float32) on the device instead of running-DFT sums; `rec_transform`
+        turns them into any frequency set afterwards."""
+        self.nfreq = 0
+        self.rec_every, self.rec_nsamples = int(every), int(nsamples)
+        self._ck(self.lib.fdtd_set_recorder(self._ctx, int(every), int(nsamples)), "set_recorder")
+
+    def rec_transform(self, bid: int, tw: np.ndarray):
+        """(complex128 [nfreq][kk][jj][ii], lo_own, hi_own) of a recorded box for the twiddle table tw
+        [nsamples][nfreq][2] of the box's field kind."""
+        tw = _arr(tw, np.float64)
+        if tw.ndim != 3 or tw.shape[2] != 2 or tw.shape[0] != self.rec_nsamples:
+            raise ValueError("twiddles must be [nsamples][nfreq][2]")
+        nf = tw.shape[1]
+        lo, hi = np.zeros(3, np.int32), np.zeros(3, np.int32)
+        self._ck(self.lib.fdtd_rec_transform(self._ctx, bid, nf, None, None, _ptr(lo), _ptr(hi)), "rec_transform")
+        ext = hi - lo + 1
+        if np.any(ext <= 0):
+            return np.zeros((nf, 0, 0, 0), np.complex128), lo, hi
+        out = np.zeros((nf, ext[2], ext[1], ext[0], 2), np.float64)
+        self._ck(self.lib.fdtd_rec_transform(self._ctx, bid, nf, _ptr(tw), _ptr(out), _ptr(lo), _ptr(hi)), "rec_transform")
+        return out[..., 0] + 1j * out[..., 1], lo, hi
 
     def add_dft_box(self, kind, comp, lo, hi) -> int:
         lo, hi = _arr(lo, np.int32), _arr(hi, np.int32)

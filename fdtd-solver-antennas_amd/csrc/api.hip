@@ -11,7 +11,7 @@
 #include <chrono>
 #include <vector>
 
-#include "fdtd_ctx.h"
+#include "kernel_common.hpp"   // fdtd_ctx.h + the device helpers of the mailbox protocol (self-test kernels below)
 
 static thread_local std::string g_err;
 
@@ -218,7 +218,7 @@ void fdtd_destroy(fdtd_ctx* c) {
   for (int q = 0; q < c->nprobe; ++q) {
     hipFree((void*)c->probe[q].off); hipFree((void*)c->probe[q].comp); hipFree((void*)c->probe[q].w); hipFree(c->probe[q].series);
   }
-  for (int b = 0; b < c->nbox; ++b) hipFree(c->box[b].acc);
+  for (int b = 0; b < c->nbox; ++b) { hipFree(c->box[b].acc); hipFree(c->box[b].rec); }
   hipFree(c->d_probe); hipFree(c->d_box); hipFree(c->tw_v); hipFree(c->tw_i);
   hipFree(c->d_energy); hipFree(c->src_rng); hipFree(c->src_ids); hipFree(c->src_rng2); hipFree(c->src_ids2);
   hipFree(c->src_rng3); hipFree(c->src_ids3); hipFree(c->src_rng4); hipFree(c->src_ids4);
@@ -517,9 +517,20 @@ int fdtd_set_dft(fdtd_ctx* c, int nfreq, int every, int nsamples, const double* 
   return FDTD_OK;
 }
 
+// Time-domain recording instead of running sums: the boxes keep their raw samples in HBM and fdtd_rec_transform turns them
+// into any frequency set afterwards — what CalcNF2FF(sim_path, f, ...) does with the engine's dumps (fixed.py:220,296).
+int fdtd_set_recorder(fdtd_ctx* c, int every, int nsamples) {
+  if (!c || every < 1 || nsamples < 1) return fdtd_fail(c, FDTD_E_ARG, "bad recorder setup");
+  if (c->nbox) return fdtd_fail(c, FDTD_E_STATE, "set_recorder must precede add_dft_box");
+  HIPCK(c, hipSetDevice(c->d.device));
+  hipFree(c->tw_v); hipFree(c->tw_i); c->tw_v = c->tw_i = nullptr;
+  c->nfreq = 0; c->recorder = true; c->every = every; c->nsamples = nsamples;
+  return FDTD_OK;
+}
+
 int fdtd_add_dft_box(fdtd_ctx* c, int kind, int comp, const int32_t lo[3], const int32_t hi[3], int* id_out) {
   if (!c || !lo || !hi || comp < 0 || comp > 2 || (kind != 0 && kind != 1)) return fdtd_fail(c, FDTD_E_ARG, "bad dft box");
-  if (!c->nfreq) return fdtd_fail(c, FDTD_E_STATE, "set_dft first");
+  if (!c->nfreq && !c->recorder) return fdtd_fail(c, FDTD_E_STATE, "set_dft or set_recorder first");
   if (c->nbox >= FDTD_MAX_BOXES) return fdtd_fail(c, FDTD_E_NOMEM, "too many dft boxes");
   HIPCK(c, hipSetDevice(c->d.device));
   const int dims[3] = {c->d.nx, c->d.ny, c->d.nz};
@@ -536,9 +547,18 @@ int fdtd_add_dft_box(fdtd_ctx* c, int kind, int comp, const int32_t lo[3], const
     bx.lo[0] = olo[0]; bx.lo[1] = olo[1]; bx.lo[2] = olo[2] - c->d.k0;
     bx.ni = ohi[0] - olo[0] + 1; bx.nj = ohi[1] - olo[1] + 1; bx.nkk = ohi[2] - olo[2] + 1;
     bx.npts = (long)bx.ni * bx.nj * bx.nkk;
-    const size_t bytes = (size_t)bx.npts * c->nfreq * 2 * sizeof(double);
-    HIPCK(c, hipMalloc(&bx.acc, bytes));
-    HIPCK(c, hipMemset(bx.acc, 0, bytes));
+    if (c->recorder) {
+      const size_t bytes = (size_t)bx.npts * (size_t)c->nsamples * sizeof(float);
+      if (hipMalloc(&bx.rec, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        bx = DevBox{};
+        return fdtd_fail(c, FDTD_E_NOMEM, "recorder box: %zu bytes of device memory (%ld points x %d samples); use fdtd_set_dft", bytes, (long)((ohi[0] - olo[0] + 1) * (long)(ohi[1] - olo[1] + 1) * (ohi[2] - olo[2] + 1)), c->nsamples);
+      }
+    } else {
+      const size_t bytes = (size_t)bx.npts * c->nfreq * 2 * sizeof(double);
+      HIPCK(c, hipMalloc(&bx.acc, bytes));
+      HIPCK(c, hipMemset(bx.acc, 0, bytes));
+    }
     c->box_maxpts[kind] = std::max(c->box_maxpts[kind], bx.npts);
   }
   if (id_out) *id_out = b;
@@ -552,10 +572,36 @@ int fdtd_get_dft_box(fdtd_ctx* c, int id, double* out, int32_t lo_own[3], int32_
   HIPCK(c, hipSetDevice(c->d.device));
   for (int a = 0; a < 3; ++a) { if (lo_own) lo_own[a] = c->box_lo[id][a]; if (hi_own) hi_own[a] = c->box_hi[id][a]; }
   const DevBox& bx = c->box[id];
+  if (out && c->recorder) return fdtd_fail(c, FDTD_E_STATE, "recorder mode: use fdtd_rec_transform");
   if (out && bx.npts) {
     HIPCK(c, hipStreamSynchronize(c->stream));
     HIPCK(c, hipMemcpy(out, bx.acc, (size_t)bx.npts * c->nfreq * 2 * sizeof(double), hipMemcpyDeviceToHost));
   }
+  return FDTD_OK;
+}
+
+int fdtd_rec_transform(fdtd_ctx* c, int id, int nfreq, const double* tw, double* out, int32_t lo_own[3], int32_t hi_own[3]) {
+  if (!c || id < 0 || id >= c->nbox) return fdtd_fail(c, FDTD_E_ARG, "bad box id");
+  if (!c->recorder) return fdtd_fail(c, FDTD_E_STATE, "not in recorder mode");
+  for (int a = 0; a < 3; ++a) { if (lo_own) lo_own[a] = c->box_lo[id][a]; if (hi_own) hi_own[a] = c->box_hi[id][a]; }
+  const DevBox& bx = c->box[id];
+  if (!out || !bx.npts) return FDTD_OK;
+  if (nfreq < 1 || !tw) return fdtd_fail(c, FDTD_E_ARG, "bad transform");
+  HIPCK(c, hipSetDevice(c->d.device));
+  // samples taken so far: steps 0, every, 2*every, ... of the half-steps already done
+  const int ns = (int)std::min<int64_t>((c->step + c->every - 1) / c->every, c->nsamples);
+  double *d_tw = nullptr, *d_out = nullptr;
+  const size_t tw_bytes = (size_t)std::max(ns, 1) * nfreq * 2 * sizeof(double), out_bytes = (size_t)bx.npts * nfreq * 2 * sizeof(double);
+  hipError_t e = hipMalloc(&d_tw, tw_bytes);
+  if (e == hipSuccess) e = hipMalloc(&d_out, out_bytes);
+  if (e == hipSuccess && ns > 0) e = hipMemcpyAsync(d_tw, tw, (size_t)ns * nfreq * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    launch_rec_dft(bx.rec, bx.npts, ns, nfreq, d_tw, d_out, c->stream);
+    e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_tw); hipFree(d_out);
+  HIPCK(c, e);
   return FDTD_OK;
 }
 
@@ -762,7 +808,7 @@ static int phase_E(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
   const long long step = c->step;
   hipStream_t s = c->stream;
   launch_mur(c, 0, s);
-  if (pe) HIPCK(c, hipEventRecord(pe->e0[n], s));
+  if (pe) { c->kev0 = pe->e0[n]; c->kev1 = pe->e1[n]; }   // the first main launch below carries them (kernel begin / end timestamps)
   const bool lower = multi && c->d.rank > 0;           // plane 0 reads the H ghost and is the plane that leaves
   const bool split = lower && overlap_split(c);
   auto wait_halo = [&]() -> int {
@@ -773,7 +819,7 @@ static int phase_E(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
   };
   if (!split) { int r = wait_halo(); if (r) return r; }
   launch_update_E(c, split ? 1 : 0, nk, step, fused, true, s);
-  if (pe) HIPCK(c, hipEventRecord(pe->e1[n], s));
+  c->kev0 = c->kev1 = nullptr;
   if (split) {
     int r = wait_halo();
     if (r) return r;
@@ -792,7 +838,7 @@ static int phase_H(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
   const int nk = c->d.nk;
   const long long step = c->step;
   hipStream_t s = c->stream;
-  if (pe) HIPCK(c, hipEventRecord(pe->h0[n], s));
+  if (pe) { c->kev0 = pe->h0[n]; c->kev1 = pe->h1[n]; }
   const bool upper = multi && c->d.rank < c->d.world - 1;   // top plane reads the E ghost and is the plane that leaves
   const bool split = upper && overlap_split(c);
   auto wait_halo = [&]() -> int {
@@ -802,7 +848,7 @@ static int phase_H(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
   };
   if (!split) { int r = wait_halo(); if (r) return r; }
   launch_update_H(c, 0, split ? nk - 1 : nk, step, fused, s);
-  if (pe) HIPCK(c, hipEventRecord(pe->h1[n], s));
+  c->kev0 = c->kev1 = nullptr;
   if (split) {
     int r = wait_halo();
     if (r) return r;
@@ -850,17 +896,17 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
 // no communication stream, no events, no RCCL call; neighbouring ranks couple only through the mailbox flags.
 static int p2p_enqueue_E(fdtd_ctx* c, ProfEvents* pe, int n) {
   HIPCK(c, hipSetDevice(c->d.device));
-  if (pe) HIPCK(c, hipEventRecord(pe->e0[n], c->stream));
+  if (pe) { c->kev0 = pe->e0[n]; c->kev1 = pe->e1[n]; }
   launch_update_E(c, 0, c->d.nk, c->step, true, true, c->stream);
-  if (pe) HIPCK(c, hipEventRecord(pe->e1[n], c->stream));
+  c->kev0 = c->kev1 = nullptr;
   launch_dft(c, FDTD_KIND_V, c->step, c->stream);
   return FDTD_OK;
 }
 static int p2p_enqueue_H(fdtd_ctx* c, ProfEvents* pe, int n) {
   HIPCK(c, hipSetDevice(c->d.device));
-  if (pe) HIPCK(c, hipEventRecord(pe->h0[n], c->stream));
+  if (pe) { c->kev0 = pe->h0[n]; c->kev1 = pe->h1[n]; }
   launch_update_H(c, 0, c->d.nk, c->step, true, c->stream);
-  if (pe) HIPCK(c, hipEventRecord(pe->h1[n], c->stream));
+  c->kev0 = c->kev1 = nullptr;
   launch_dft(c, FDTD_KIND_I, c->step, c->stream);
   return FDTD_OK;
 }
@@ -920,57 +966,60 @@ int fdtd_run(fdtd_ctx* c, int nsteps) {
 int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
   int r = check_ready(c);
   if (r) return r;
-  if (!out || nsteps < 1 || nsteps > 20000) return fdtd_fail(c, FDTD_E_ARG, "profiled run: 1..20000 steps");
+  if (!out || nsteps < 1 || nsteps > 4096) return fdtd_fail(c, FDTD_E_ARG, "profiled run: 1..4096 steps (four events per step)");
   HIPCK(c, hipSetDevice(c->d.device));
   ProfEvents pe;
-  auto mk = [&](std::vector<hipEvent_t>& v) { v.resize(nsteps); for (auto& e : v) hipEventCreate(&e); };
-  mk(pe.e0); mk(pe.e1); mk(pe.h0); mk(pe.h1);
-  hipEventCreate(&pe.t0); hipEventCreate(&pe.t1);
-  HIPCK(c, hipStreamSynchronize(c->stream));
-  HIPCK(c, hipEventRecord(pe.t0, c->stream));
-  r = step_loop(c, nsteps, &pe);
-  if (r == FDTD_OK) {
-    hipEventRecord(pe.t1, c->stream);
-    hipStreamSynchronize(c->stream);
-    hipStreamSynchronize(c->comm_stream);
+  auto destroy_all = [&]() {
+    for (auto* v : {&pe.e0, &pe.e1, &pe.h0, &pe.h1}) for (auto e : *v) if (e) hipEventDestroy(e);
+    if (pe.t0) hipEventDestroy(pe.t0);
+    if (pe.t1) hipEventDestroy(pe.t1);
+  };
+  hipError_t ce = hipSuccess;
+  for (auto* v : {&pe.e0, &pe.e1, &pe.h0, &pe.h1}) {
+    v->assign(nsteps, nullptr);
+    for (auto& e : *v) if (ce == hipSuccess) ce = hipEventCreate(&e);
+  }
+  if (ce == hipSuccess) ce = hipEventCreate(&pe.t0);
+  if (ce == hipSuccess) ce = hipEventCreate(&pe.t1);
+  if (ce != hipSuccess) {
+    destroy_all();
+    return fdtd_fail(c, FDTD_E_DEVICE, "profiled run: hipEventCreate: %s", hipGetErrorString(ce));
+  }
+  r = FDTD_OK;
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipEventRecord(pe.t0, c->stream);
+  if (e == hipSuccess) r = step_loop(c, nsteps, &pe);
+  c->kev0 = c->kev1 = nullptr;
+  if (e == hipSuccess && r == FDTD_OK) {
+    e = hipEventRecord(pe.t1, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->comm_stream);
+  }
+  if (e == hipSuccess && r == FDTD_OK) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, pe.t0, pe.t1);
     memset(out, 0, sizeof(*out));
     out->ms_total = ms; out->steps = nsteps;
+    // Two-pass kernels: every main launch carried its own start / stop events (hipExtLaunchKernelGGL), which take the
+    // dispatch's begin and end timestamps — the interval a kernel trace reports, no event-packet time inside, nothing
+    // to calibrate away.  (One-pass kernels are bracketed by ordinary event records.)
     double se = 0, sh = 0;
-    for (int n = 0; n < nsteps; ++n) {
-      hipEventElapsedTime(&ms, pe.e0[n], pe.e1[n]); se += ms;
-      hipEventElapsedTime(&ms, pe.h0[n], pe.h1[n]); sh += ms;
-    }
-    // fixed cost of timing ONE launch with an event pair: the same pair with nothing between, same stream (the
-    // event packets' own processing time); subtracted so that the figure is the kernel's begin-to-end duration
-    // as rocprofv3 reports it (an empty kernel there still lasts ~3.6 us, which is real per-launch cost and stays in)
-    double ov = 0.0;
-    {
-      const int reps = 64, lead = 8;     // all pairs queued back to back (steady state, like the step loop), one sync
-      std::vector<hipEvent_t> a(reps + lead), b(reps + lead);
-      for (auto& e : a) hipEventCreate(&e);
-      for (auto& e : b) hipEventCreate(&e);
-      for (int q = 0; q < reps + lead; ++q) {
-        hipEventRecord(a[q], c->stream);
-        hipEventRecord(b[q], c->stream);
-      }
-      hipStreamSynchronize(c->stream);
-      for (int q = lead; q < reps + lead; ++q) { hipEventElapsedTime(&ms, a[q], b[q]); ov += ms; }
-      ov /= reps;
-      for (auto e : a) hipEventDestroy(e);
-      for (auto e : b) hipEventDestroy(e);
-    }
-    out->ms_event_overhead = ov;
-    out->ms_update_e = std::max(0.0, se / nsteps - ov);
     const bool one_pass = one_pass_mode(c->d.flags & FDTD_FLAG_KERNEL_MASK);
-    out->ms_update_h = one_pass ? 0.0 : std::max(0.0, sh / nsteps - ov);
-    out->fused = one_pass_mode(c->d.flags & FDTD_FLAG_KERNEL_MASK) ? 1 : 0;
+    for (int n = 0; n < nsteps; ++n) {
+      if (hipEventElapsedTime(&ms, pe.e0[n], pe.e1[n]) == hipSuccess) se += ms;
+      if (!one_pass && hipEventElapsedTime(&ms, pe.h0[n], pe.h1[n]) == hipSuccess) sh += ms;
+    }
+    (void)hipGetLastError();
+    out->ms_event_overhead = 0.0;
+    out->ms_update_e = se / nsteps;
+    out->ms_update_h = one_pass ? 0.0 : sh / nsteps;
+    out->fused = one_pass ? 1 : 0;
     out->launches_e = out->launches_h = nsteps;
   }
-  for (auto* v : {&pe.e0, &pe.e1, &pe.h0, &pe.h1}) for (auto e : *v) hipEventDestroy(e);
-  hipEventDestroy(pe.t0); hipEventDestroy(pe.t1);
-  return r;
+  destroy_all();
+  if (r) return r;
+  HIPCK(c, e);
+  return FDTD_OK;
 }
 
 int fdtd_get_step(fdtd_ctx* c, int64_t* step) {
@@ -1104,7 +1153,27 @@ static int p2p_open(fdtd_ctx* c, const void* blob128, void** out, bool* ipc) {
   P2pBlob b;
   memcpy(&b, blob128, sizeof(b));
   if (b.nx != c->d.nx || b.ny != c->d.ny || b.bytes != c->mbox_bytes) return fdtd_fail(c, FDTD_E_ARG, "p2p: neighbour mailbox belongs to another grid");
-  if (b.pid == (int32_t)getpid()) { *out = (void*)(uintptr_t)b.raw; *ipc = false; return FDTD_OK; }   // same process: the pointer itself
+  if (b.pid == (int32_t)getpid()) {   // same process: the pointer itself — on another device only through peer access
+    if (b.device != c->d.device) {
+      int can = 0;
+      HIPCK(c, hipDeviceCanAccessPeer(&can, c->d.device, b.device));
+      if (!can) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "p2p: device %d cannot access device %d (no peer path); use the rccl or host transport", c->d.device, b.device);
+      const int pair[2][2] = {{c->d.device, b.device}, {b.device, c->d.device}};
+      for (int q = 0; q < 2; ++q) {
+        HIPCK(c, hipSetDevice(pair[q][0]));
+        const hipError_t e = hipDeviceEnablePeerAccess(pair[q][1], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+          (void)hipGetLastError();
+          hipSetDevice(c->d.device);
+          return fdtd_fail(c, FDTD_E_UNSUPPORTED, "p2p: enabling peer access %d -> %d failed: %s", pair[q][0], pair[q][1], hipGetErrorString(e));
+        }
+        (void)hipGetLastError();
+      }
+      HIPCK(c, hipSetDevice(c->d.device));
+    }
+    *out = (void*)(uintptr_t)b.raw; *ipc = false;
+    return FDTD_OK;
+  }
   HIPCK(c, hipIpcOpenMemHandle(out, b.h, hipIpcMemLazyEnablePeerAccess));
   *ipc = true;
   return FDTD_OK;
@@ -1117,6 +1186,9 @@ int fdtd_p2p_attach(fdtd_ctx* c, const void* lower128, const void* upper128) {
   if ((c->d.rank > 0) != (lower128 != nullptr) || (c->d.rank < c->d.world - 1) != (upper128 != nullptr))
     return fdtd_fail(c, FDTD_E_ARG, "p2p: rank %d of %d needs exactly its existing neighbours' blobs", c->d.rank, c->d.world);
   if (c->comm || c->link_lo || c->link_hi) return fdtd_fail(c, FDTD_E_STATE, "p2p: another halo transport is already attached");
+  // the mailbox flags count steps from zero (a kernel waits for flag >= step): a context that has already stepped
+  // would wait 10 s for halos nobody sends and then go on with an empty mailbox
+  if (c->step != 0) return fdtd_fail(c, FDTD_E_STATE, "p2p: attach before the first timestep (context is at step %lld)", (long long)c->step);
   int r = p2p_alloc(c);
   if (r) return r;
   HIPCK(c, hipSetDevice(c->d.device));
@@ -1160,46 +1232,107 @@ int fdtd_p2p_attach(fdtd_ctx* c, const void* lower128, const void* upper128) {
   return FDTD_OK;
 }
 
-// Hand-shake over the attached mailboxes: every rank writes a token into its neighbours' control words and waits
-// (bounded, 10 s) for theirs — proves that the peer mappings are writable and that system-scope stores and polls
-// cross the link, before any timestep depends on it.  Call on all ranks at about the same time.
-__global__ void k_p2p_selftest(const DevParams p, const unsigned token, int* result) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  unsigned* mine = p.fl_in;
-  if (p.fl_out_E) __hip_atomic_store(p.fl_out_E + 8 + 1, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);        // lower's "from upper" slot
-  if (p.fl_out_H) __hip_atomic_store((p.fl_out_H - 1) + 8 + 0, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // upper's "from lower" slot
-  const unsigned long long t0 = wall_clock64();
-  int ok = 1;
-  for (int side = 0; side < 2; ++side) {
-    const bool have = side == 0 ? p.mb_in_H != nullptr : p.mb_in_E != nullptr;   // lower / upper neighbour exists
-    if (!have) continue;
-    while (__hip_atomic_load(mine + 8 + side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != token) {
-      __builtin_amdgcn_s_sleep(16);
-      if ((unsigned long long)wall_clock64() - t0 > p.p2p_limit) { ok = 0; break; }
+// Self-test over the attached mailboxes, THROUGH THE DATA PATH of the update kernels: every rank fills both parities of
+// both halo planes in its neighbours' mailboxes with a token-derived pattern using the same 16-byte write-through
+// stores (st4_sys), drains them (vmcnt) and publishes the token; then it waits (bounded, 10 s) for its neighbours'
+// tokens and reads its own mailbox back with the same cache-bypassing 16-byte loads (ld4_sys), comparing every word.
+// A link on which flags cross but payload stores lag, tear or vanish fails here instead of corrupting halos.
+// Two launches (post, then wait + verify), so that a grid larger than the chip can never wait on its own blocks.
+// Call on all ranks at about the same time.
+__device__ __forceinline__ float4 p2p_pattern(const unsigned token, const unsigned dir, const unsigned slot, const unsigned t) {
+  const unsigned h = (token * 2654435761u) ^ (dir * 0x9E3779B9u) ^ (slot * 0x85EBCA6Bu) ^ (t * 0xC2B2AE35u);
+  // finite float bit patterns only (exponent field forced into the normal range): the words are never computed on
+  const unsigned m = 0x807FFFFFu, e = 0x3F000000u;
+  return make_float4(__uint_as_float(((h) & m) | e), __uint_as_float(((h * 3u + 1u) & m) | e),
+                     __uint_as_float(((h * 5u + 2u) & m) | e), __uint_as_float(((h * 7u + 3u) & m) | e));
+}
+
+__global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_selftest_post(const DevParams p, const unsigned token) {
+  const unsigned t = blockIdx.x * FDTD_BLOCK + threadIdx.x, n4 = (unsigned)p.plane / 4u;
+  if (t < n4) {
+    for (unsigned slot = 0; slot < 4u; ++slot) {   // slot = parity * 2 + component
+      if (p.mb_out_E) st4_sys(p.mb_out_E + (size_t)slot * p.plane + 4u * t, p2p_pattern(token, 0u, slot, t));
+      if (p.mb_out_H) st4_sys(p.mb_out_H + (size_t)slot * p.plane + 4u * t, p2p_pattern(token, 1u, slot, t));
     }
   }
-  *result = ok;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores ...
+  __syncthreads();                                    // ... before ONE lane signals for the whole workgroup
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(p.p2p_cnt + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (old == gridDim.x - 1u) {
+      __hip_atomic_store(p.p2p_cnt + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (p.fl_out_E) __hip_atomic_store(p.fl_out_E + 8 + 1, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);        // lower's "from upper" slot
+      if (p.fl_out_H) __hip_atomic_store((p.fl_out_H - 1) + 8 + 0, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // upper's "from lower" slot
+    }
+  }
+}
+
+// result[0]: blocks that timed out waiting for a token; result[1]: float4 groups that read back wrong
+__global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_selftest_verify(const DevParams p, const unsigned token, unsigned* result) {
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
+    int ok = 1;
+    for (int side = 0; side < 2 && ok; ++side) {
+      const bool have = side == 0 ? p.mb_in_H != nullptr : p.mb_in_E != nullptr;   // lower / upper neighbour exists
+      if (!have) continue;
+      while (__hip_atomic_load(p.fl_in + 8 + side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != token) {
+        __builtin_amdgcn_s_sleep(16);
+        if ((unsigned long long)wall_clock64() - t0 > p.p2p_limit) { ok = 0; break; }
+      }
+    }
+    s_ok = ok;
+    if (!ok) atomicAdd(result + 0, 1u);
+  }
+  __syncthreads();
+  if (!s_ok) return;
+  const unsigned t = blockIdx.x * FDTD_BLOCK + threadIdx.x, n4 = (unsigned)p.plane / 4u;
+  if (t >= n4) return;
+  unsigned bad = 0;
+  for (unsigned slot = 0; slot < 4u; ++slot) {
+    if (p.mb_in_E) {   // written by the upper neighbour as ITS E-down halo (dir 0)
+      const float4 g = ld4_sys(p.mb_in_E + (size_t)slot * p.plane + 4u * t), w = p2p_pattern(token, 0u, slot, t);
+      bad += (__float_as_uint(g.x) != __float_as_uint(w.x)) | (__float_as_uint(g.y) != __float_as_uint(w.y)) |
+             (__float_as_uint(g.z) != __float_as_uint(w.z)) | (__float_as_uint(g.w) != __float_as_uint(w.w));
+    }
+    if (p.mb_in_H) {   // written by the lower neighbour as ITS H-up halo (dir 1)
+      const float4 g = ld4_sys(p.mb_in_H + (size_t)slot * p.plane + 4u * t), w = p2p_pattern(token, 1u, slot, t);
+      bad += (__float_as_uint(g.x) != __float_as_uint(w.x)) | (__float_as_uint(g.y) != __float_as_uint(w.y)) |
+             (__float_as_uint(g.z) != __float_as_uint(w.z)) | (__float_as_uint(g.w) != __float_as_uint(w.w));
+    }
+  }
+  if (bad) atomicAdd(result + 1, bad);
 }
 
 int fdtd_p2p_selftest(fdtd_ctx* c, unsigned token) {
   if (!c) return FDTD_E_ARG;
   if (!c->p.p2p) return fdtd_fail(c, FDTD_E_STATE, "p2p transport not attached");
+  if (c->step != 0) return fdtd_fail(c, FDTD_E_STATE, "p2p self-test overwrites the mailboxes: run it before the first timestep");
+  if (token == 0u) return fdtd_fail(c, FDTD_E_ARG, "p2p self-test token must be non-zero");
   HIPCK(c, hipSetDevice(c->d.device));
-  int* d_res = nullptr;
-  HIPCK(c, hipMalloc(&d_res, sizeof(int)));
-  HIPCK(c, hipMemsetAsync(d_res, 0, sizeof(int), c->stream));   // the context's stream is non-blocking: keep everything on it
-  hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(64), 0, c->stream, c->p, token, d_res);
-  int res = 0;
-  hipError_t e = hipMemcpyAsync(&res, d_res, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+  unsigned* d_res = nullptr;
+  HIPCK(c, hipMalloc(&d_res, 2 * sizeof(unsigned)));
+  HIPCK(c, hipMemsetAsync(d_res, 0, 2 * sizeof(unsigned), c->stream));   // the context's stream is non-blocking: keep everything on it
+  const unsigned nb = (unsigned)((c->plane / 4 + FDTD_BLOCK - 1) / FDTD_BLOCK);
+  hipLaunchKernelGGL(k_p2p_selftest_post, dim3(nb), dim3(FDTD_BLOCK), 0, c->stream, c->p, token);
+  hipLaunchKernelGGL(k_p2p_selftest_verify, dim3(nb), dim3(FDTD_BLOCK), 0, c->stream, c->p, token, d_res);
+  unsigned res[2] = {0, 0};
+  hipError_t e = hipMemcpyAsync(res, d_res, sizeof(res), hipMemcpyDeviceToHost, c->stream);
+  // all neighbours' pattern stores into THIS mailbox were acknowledged before their tokens arrived: restore the zeros
+  // the first timestep expects (the halo of "step -1" is the zero initial field), leave flags and counters alone
+  if (e == hipSuccess) e = hipMemsetAsync(c->mbox, 0, p2p_floats(c) * sizeof(float), c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   hipFree(d_res);
   HIPCK(c, e);
-  if (!res) {
+  if (res[0]) {
     unsigned slots[2] = {0, 0};
     hipMemcpy(slots, c->p.fl_in + 8, sizeof(slots), hipMemcpyDeviceToHost);
     return fdtd_fail(c, FDTD_E_DEVICE, "p2p self-test: no token from a neighbour within the time limit (expected %#x; mailbox now holds from-lower %#x, from-upper %#x)",
                      token, slots[0], slots[1]);
   }
+  if (res[1])
+    return fdtd_fail(c, FDTD_E_DEVICE, "p2p self-test: %u of %u 16-byte halo groups read back wrong although the neighbour's token arrived (payload stores do not reach this mailbox in order)",
+                     res[1], (unsigned)(c->plane / 4) * 4u * ((c->p.mb_in_E ? 1u : 0u) + (c->p.mb_in_H ? 1u : 0u)));
   return FDTD_OK;
 }
 

@@ -95,7 +95,7 @@ struct DevParams {
 };
 
 struct DevProbe { int kind, n; const int* off; const int8_t* comp; const float* w; double* series; };
-struct DevBox   { int kind, comp; int lo[3]; int ni, nj, nkk; double* acc; long npts; };
+struct DevBox   { int kind, comp; int lo[3]; int ni, nj, nkk; double* acc; long npts; float* rec; /* recorder: [nsamples][npts] */ };
 
 struct MurFace { int on; float coeff; float* st[2]; int n; };
 
@@ -142,6 +142,7 @@ struct fdtd_ctx {
   int nprobe = 0; DevProbe probe[FDTD_MAX_PROBES] = {}; DevProbe* d_probe = nullptr;
   // dft
   int nfreq = 0, every = 0, nsamples = 0; double *tw_v = nullptr, *tw_i = nullptr;
+  bool recorder = false;         // boxes keep time-domain samples (fdtd_set_recorder) instead of running-DFT sums
   int nbox = 0; DevBox box[FDTD_MAX_BOXES] = {}; DevBox* d_box = nullptr;
   int32_t box_lo[FDTD_MAX_BOXES][3] = {}, box_hi[FDTD_MAX_BOXES][3] = {};
   long box_maxpts[2] = {0, 0};
@@ -156,6 +157,7 @@ struct fdtd_ctx {
   fdtd_ctx* link_hi = nullptr;
   bool haloE_issued = false, haloH_issued = false;
   bool tables_dirty = true;
+  hipEvent_t kev0 = nullptr, kev1 = nullptr;   // profiled run: start / stop events the next main launch carries
   std::string err;
 };
 
@@ -175,7 +177,8 @@ void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool f
 void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s);
 void launch_mur(fdtd_ctx* c, int mode, hipStream_t s);
 void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_t s);   // stand-alone sources + probes
-void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);
+void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);   // running DFT or time-domain recording of the boxes
+void launch_rec_dft(const float* rec, long npts, int ns, int nfreq, const double* d_tw, double* d_out, hipStream_t s);
 // fused.hip: one launch = E half-step + H half-step of all owned planes, current -> next buffers
 void launch_step_fused(fdtd_ctx* c, long long step, bool probe_block, hipStream_t s);
 void choose_tiling_fused(fdtd_ctx* c);

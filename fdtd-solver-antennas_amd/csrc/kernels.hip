@@ -24,6 +24,8 @@
 //
 // Float32 operation order is pinned with explicit fmaf (compiled with -ffp-contract=off) and is
 // identical to oracle/fdtd_oracle.c, so results are compared bit for bit.
+#include <hip/hip_ext.h>
+
 #include "kernel_common.hpp"
 
 namespace {
@@ -33,7 +35,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // COEF: 0 raw arrays, 1 class byte per edge, 2 one packed class byte per cell
 template <int COEF, bool PML, bool FUSE, bool P2P>
-__global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const FastDiv fd_ps,
+__global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const FastDiv fd_ps,
                                                                             const long long step, const int extra, const unsigned nb_main) {
   __shared__ float2 s_lut[COEF == 2 ? 768 : (COEF == 1 ? 256 : 1)];
   __shared__ double s_red[FUSE ? FDTD_BLOCK : 1];
@@ -123,70 +125,50 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const
       cpml_x4(p, 0, i0, (k * p.ny + j) * p.nslot[0], dy2, p.psiE[1][1], dz1, p.psiE[2][0]);
   }
 
-  float4 ax, bx, ay, by, az, bz;
-  if (COEF == 0) {
-    ax = ld4(p.vv + off); bx = ld4(p.vi + off);
-    ay = ld4(p.vv + p.nloc + off); by = ld4(p.vi + p.nloc + off);
-    az = ld4(p.vv + 2 * p.nloc + off); bz = ld4(p.vi + 2 * p.nloc + off);
-  } else {
-    const float4 ex0 = ld4(p.emet[0][0] + i0), ex1 = ld4(p.emet[1][0] + i0), ex2 = ld4(p.emet[2][0] + i0);
-    const float m0 = p.emet[0][1][j] * p.emet[0][2][k];
-    const float m1 = p.emet[1][1][j] * p.emet[1][2][k];
-    const float m2 = p.emet[2][1][j] * p.emet[2][2][k];
-    float2 l0, l1, l2, l3;
-    if (COEF == 1) {
-      const uchar4 cx = *reinterpret_cast<const uchar4*>(p.ecls + off);
-      const uchar4 cy = *reinterpret_cast<const uchar4*>(p.ecls + p.nloc + off);
-      const uchar4 cz = *reinterpret_cast<const uchar4*>(p.ecls + 2 * p.nloc + off);
-      l0 = s_lut[cx.x]; l1 = s_lut[cx.y]; l2 = s_lut[cx.z]; l3 = s_lut[cx.w];
-      ax = make_float4(l0.x, l1.x, l2.x, l3.x);
-      bx = make_float4(l0.y * (ex0.x * m0), l1.y * (ex0.y * m0), l2.y * (ex0.z * m0), l3.y * (ex0.w * m0));
-      l0 = s_lut[cy.x]; l1 = s_lut[cy.y]; l2 = s_lut[cy.z]; l3 = s_lut[cy.w];
-      ay = make_float4(l0.x, l1.x, l2.x, l3.x);
-      by = make_float4(l0.y * (ex1.x * m1), l1.y * (ex1.y * m1), l2.y * (ex1.z * m1), l3.y * (ex1.w * m1));
-      l0 = s_lut[cz.x]; l1 = s_lut[cz.y]; l2 = s_lut[cz.z]; l3 = s_lut[cz.w];
-      az = make_float4(l0.x, l1.x, l2.x, l3.x);
-      bz = make_float4(l0.y * (ex2.x * m2), l1.y * (ex2.y * m2), l2.y * (ex2.z * m2), l3.y * (ex2.w * m2));
+  // One component at a time — coefficients, update, sources, store — with a scheduling fence between the components:
+  // left to itself the scheduler interleaves all three (12 LDS table reads, 3 metric float4, 6 coefficient float4 live
+  // at once), which costs the variant without CPML branches more registers than its occupancy target has (it spilled).
+  const int nsrc_t = (FUSE && srng.y > srng.x) ? min(srng.y - srng.x, FDTD_BLOCK) : 0;
+  uchar4 cc = make_uchar4(0, 0, 0, 0);
+  if (COEF == 2) cc = *reinterpret_cast<const uchar4*>(p.ecls + off);
+#pragma unroll
+  for (int comp = 0; comp < 3; ++comp) {
+    float4& v = comp == 0 ? vx : (comp == 1 ? vy : vz);
+    const float4& d1 = comp == 0 ? dx1 : (comp == 1 ? dy1 : dz1);
+    const float4& d2 = comp == 0 ? dx2 : (comp == 1 ? dy2 : dz2);
+    float4 a, b;
+    if (COEF == 0) {
+      a = ld4(p.vv + comp * p.nloc + off); b = ld4(p.vi + comp * p.nloc + off);
     } else {
-      const uchar4 cc = *reinterpret_cast<const uchar4*>(p.ecls + off);
-      const int c0 = 3 * cc.x, c1 = 3 * cc.y, c2 = 3 * cc.z, c3 = 3 * cc.w;
-      l0 = s_lut[c0]; l1 = s_lut[c1]; l2 = s_lut[c2]; l3 = s_lut[c3];
-      ax = make_float4(l0.x, l1.x, l2.x, l3.x);
-      bx = make_float4(l0.y * (ex0.x * m0), l1.y * (ex0.y * m0), l2.y * (ex0.z * m0), l3.y * (ex0.w * m0));
-      l0 = s_lut[c0 + 1]; l1 = s_lut[c1 + 1]; l2 = s_lut[c2 + 1]; l3 = s_lut[c3 + 1];
-      ay = make_float4(l0.x, l1.x, l2.x, l3.x);
-      by = make_float4(l0.y * (ex1.x * m1), l1.y * (ex1.y * m1), l2.y * (ex1.z * m1), l3.y * (ex1.w * m1));
-      l0 = s_lut[c0 + 2]; l1 = s_lut[c1 + 2]; l2 = s_lut[c2 + 2]; l3 = s_lut[c3 + 2];
-      az = make_float4(l0.x, l1.x, l2.x, l3.x);
-      bz = make_float4(l0.y * (ex2.x * m2), l1.y * (ex2.y * m2), l2.y * (ex2.z * m2), l3.y * (ex2.w * m2));
+      const float4 ex = ld4(p.emet[comp][0] + i0);
+      const float m = p.emet[comp][1][j] * p.emet[comp][2][k];
+      float2 l0, l1, l2, l3;
+      if (COEF == 1) {
+        const uchar4 c1 = *reinterpret_cast<const uchar4*>(p.ecls + comp * p.nloc + off);
+        l0 = s_lut[c1.x]; l1 = s_lut[c1.y]; l2 = s_lut[c1.z]; l3 = s_lut[c1.w];
+      } else {
+        l0 = s_lut[3 * cc.x + comp]; l1 = s_lut[3 * cc.y + comp]; l2 = s_lut[3 * cc.z + comp]; l3 = s_lut[3 * cc.w + comp];
+      }
+      a = make_float4(l0.x, l1.x, l2.x, l3.x);
+      b = make_float4(l0.y * (ex.x * m), l1.y * (ex.y * m), l2.y * (ex.z * m), l3.y * (ex.w * m));
     }
-  }
-  vx = upd4(ax, vx, bx, dx1, dx2);
-  vy = upd4(ay, vy, by, dy1, dy2);
-  vz = upd4(az, vz, bz, dz1, dz2);
-  if (FUSE && srng.y > srng.x) {
-    // V += amp * sig[step - delay] on the edges of this strip-plane: the first FDTD_BLOCK from the LDS stage,
-    // any overflow (never seen in the reference's scenes) straight from global memory
-    const int n = min(srng.y - srng.x, FDTD_BLOCK);
-    apply_staged(s_src, n, 0, off, vx);
-    apply_staged(s_src, n, 1, off, vy);
-    apply_staged(s_src, n, 2, off, vz);
-    for (int q = srng.x + FDTD_BLOCK; q < srng.y; ++q) {
-      const int e = p.src_ids[q];
-      const unsigned rel = (unsigned)(p.src_off[e] - off);
-      if (rel < 4u) {
-        const long long t = step - p.src_delay[e];
-        if (t >= 0 && t < p.nsig) {
-          const float a = p.src_amp[e] * p.sig[t];
-          const int cmp = p.src_comp[e];
-          if (cmp == 0) add_elem(vx, (int)rel, a); else if (cmp == 1) add_elem(vy, (int)rel, a); else add_elem(vz, (int)rel, a);
+    v = upd4(a, v, b, d1, d2);
+    if (FUSE && nsrc_t > 0) {
+      // V += amp * sig[step - delay] on the edges of this strip-plane: the first FDTD_BLOCK from the LDS stage,
+      // any overflow (never seen in the reference's scenes) straight from global memory
+      apply_staged(s_src, nsrc_t, comp, off, v);
+      for (int q = srng.x + FDTD_BLOCK; q < srng.y; ++q) {
+        const int e = p.src_ids[q];
+        const unsigned rel = (unsigned)(p.src_off[e] - off);
+        if (rel < 4u && p.src_comp[e] == comp) {
+          const long long t = step - p.src_delay[e];
+          if (t >= 0 && t < p.nsig) add_elem(v, (int)rel, p.src_amp[e] * p.sig[t]);
         }
       }
     }
+    sto4s(p.nt, p.V[comp], (unsigned)off, v);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  sto4s(p.nt, p.V[0], (unsigned)off, vx);
-  sto4s(p.nt, p.V[1], (unsigned)off, vy);
-  sto4s(p.nt, p.V[2], (unsigned)off, vz);
   if (P2P && k == 0 && p.mb_out_E != nullptr) {   // push the new Vx, Vy of the bottom plane into the lower rank's mailbox
     float* mb = p.mb_out_E + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
     st4_sys(mb, vx);
@@ -199,7 +181,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E(const
 // K2: H half-step
 // ------------------------------------------------------------------------------------------------
 template <bool RAW, bool PML, bool P2P>
-__global__ __launch_bounds__(FDTD_BLOCK, FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const FastDiv fd_ps,
+__global__ __launch_bounds__(FDTD_BLOCK, (P2P && RAW) ? FDTD_H_MINBLOCKS - 1 : FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const FastDiv fd_ps,
                                                                             const long long step, const int extra, const unsigned nb_main) {
   __shared__ double s_red[FDTD_BLOCK];
   if (extra && blockIdx.x == gridDim.x - 1) {   // probe block: V-probes of this step (V is final, H not read)
@@ -375,6 +357,47 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_dft(const DevParams p, const int
   }
 }
 
+// K6': time-domain recording of the same boxes (fdtd_set_recorder): sample `smp` of every box of `kind` -> rec[smp][pt].
+// What the reference's engine dumps for an NF2FF box (CreateNF2FFBox, solver_fdtd_openems_fixed.py:220), kept in HBM.
+__global__ __launch_bounds__(FDTD_BLOCK) void k_rec(const DevParams p, const int kind, const DevBox* __restrict__ boxes,
+                                                    const int every, const int nsamples, const long long step) {
+  const long long smp = step / every;
+  if (step % every != 0 || smp >= nsamples) return;
+  const DevBox bx = boxes[blockIdx.y];
+  if (bx.kind != kind || bx.npts == 0) return;
+  const float* F = (kind == FDTD_KIND_V ? p.V[bx.comp] : p.I[bx.comp]);
+  float* dst = bx.rec + (size_t)smp * bx.npts;
+  for (long pt = (long)blockIdx.x * FDTD_BLOCK + threadIdx.x; pt < bx.npts; pt += (long)gridDim.x * FDTD_BLOCK) {
+    const int ii = (int)(pt % bx.ni);
+    const long r = pt / bx.ni;
+    const int jj = (int)(r % bx.nj), kk = (int)(r / bx.nj);
+    dst[pt] = F[(bx.lo[2] + kk) * p.plane + (bx.lo[1] + jj) * p.P + bx.lo[0] + ii];
+  }
+}
+
+// ... and their transform to any set of frequencies after the run (fdtd_rec_transform; what nf2ff.CalcNF2FF does with the
+// dumps, fixed.py:296): out[f][pt] = sum_s rec[s][pt] * tw[s][f], samples in order, one float64 fma chain per (f, pt) —
+// the same chain the running DFT builds, so both give identical bits.  NF frequencies per pass over the samples.
+template <int NF>
+__global__ __launch_bounds__(FDTD_BLOCK) void k_rec_dft(const float* __restrict__ rec, const long npts, const int ns, const int nfreq,
+                                                        const int f0, const double* __restrict__ tw, double* __restrict__ out) {
+  const long pt = (long)blockIdx.x * FDTD_BLOCK + threadIdx.x;
+  if (pt >= npts) return;
+  double ar[NF], ai[NF];
+#pragma unroll
+  for (int q = 0; q < NF; ++q) ar[q] = ai[q] = 0.0;
+  for (int s = 0; s < ns; ++s) {
+    const double v = (double)rec[(size_t)s * npts + pt];
+    const double* w = tw + ((size_t)s * nfreq + f0) * 2;
+#pragma unroll
+    for (int q = 0; q < NF; ++q)
+      if (f0 + q < nfreq) { ar[q] = fma(v, w[2 * q], ar[q]); ai[q] = fma(v, w[2 * q + 1], ai[q]); }
+  }
+#pragma unroll
+  for (int q = 0; q < NF; ++q)
+    if (f0 + q < nfreq) { double* o = out + ((size_t)(f0 + q) * npts + pt) * 2; o[0] = ar[q]; o[1] = ai[q]; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K8: energy sums over the owned planes (pads are zero, ghosts excluded).
 // ------------------------------------------------------------------------------------------------
@@ -433,18 +456,26 @@ static unsigned lds_pad(int cap, unsigned static_bytes) {
   return total > static_bytes ? total - static_bytes : 0;
 }
 
+// Main-kernel launch; in a profiled run (fdtd_run_profiled) the launch carries start / stop events that receive the
+// dispatch's own begin and end timestamps.
+template <typename K, typename... A>
+static void launch_main(fdtd_ctx* c, K kern, dim3 grid, unsigned lds, hipStream_t s, A... args) {
+  if (c->kev0) hipExtLaunchKernelGGL(kern, grid, dim3(FDTD_BLOCK), lds, s, c->kev0, c->kev1, 0, args...);
+  else hipLaunchKernelGGL(kern, grid, dim3(FDTD_BLOCK), lds, s, args...);
+}
+
 template <int COEF, bool PML>
 static void launch_E2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long step, bool fused, int extra, hipStream_t s) {
   const unsigned pad = lds_pad(c->occ_e, 11264u);
   if (c->p.p2p) {   // whole slab in one launch, bottom plane last (decode_block_p2p)
     const FastDiv fd_ps = make_fastdiv((unsigned)(nkr - 1) * (unsigned)c->p.nbs);
     const unsigned nb_main = (unsigned)c->p.nstrips * (unsigned)(nkr - 1) * (unsigned)c->p.nbs;
-    hipLaunchKernelGGL((k_update_E<COEF, PML, true, true>), grid, dim3(FDTD_BLOCK), pad, s, c->p, 0, fd_ps, step, extra, nb_main);
+    launch_main(c, k_update_E<COEF, PML, true, true>, grid, pad, s, c->p, 0, fd_ps, step, extra, nb_main);
     return;
   }
   const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
-  if (fused) hipLaunchKernelGGL((k_update_E<COEF, PML, true, false>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, fd_ps, step, extra, 0u);
-  else hipLaunchKernelGGL((k_update_E<COEF, PML, false, false>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, fd_ps, step, 0, 0u);
+  if (fused) launch_main(c, k_update_E<COEF, PML, true, false>, grid, pad, s, c->p, k_begin, fd_ps, step, extra, 0u);
+  else launch_main(c, k_update_E<COEF, PML, false, false>, grid, pad, s, c->p, k_begin, fd_ps, step, 0, 0u);
 }
 
 void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool fused, bool probe_block, hipStream_t s) {
@@ -470,11 +501,11 @@ static void launch_H2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long st
   if (c->p.p2p) {
     const FastDiv fd_ps = make_fastdiv((unsigned)(nkr - 1) * (unsigned)c->p.nbs);
     const unsigned nb_main = (unsigned)c->p.nstrips * (unsigned)(nkr - 1) * (unsigned)c->p.nbs;
-    hipLaunchKernelGGL((k_update_H<RAW, PML, true>), grid, dim3(FDTD_BLOCK), pad, s, c->p, 0, fd_ps, step, extra, nb_main);
+    launch_main(c, k_update_H<RAW, PML, true>, grid, pad, s, c->p, 0, fd_ps, step, extra, nb_main);
     return;
   }
   const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
-  hipLaunchKernelGGL((k_update_H<RAW, PML, false>), grid, dim3(FDTD_BLOCK), pad, s, c->p, k_begin, fd_ps, step, extra, 0u);
+  launch_main(c, k_update_H<RAW, PML, false>, grid, pad, s, c->p, k_begin, fd_ps, step, extra, 0u);
 }
 
 void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s) {
@@ -519,12 +550,21 @@ void launch_mur(fdtd_ctx* c, int mode, hipStream_t s) {
 }
 
 void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s) {
-  if (!(c->nfreq && c->nbox && (step % c->every) == 0 && c->box_maxpts[kind] > 0)) return;
+  if (!((c->nfreq || c->recorder) && c->nbox && (step % c->every) == 0 && c->box_maxpts[kind] > 0)) return;
   const long pts = c->box_maxpts[kind];
   unsigned gx = (unsigned)((pts + FDTD_BLOCK - 1) / FDTD_BLOCK);
   if (gx > 1024) gx = 1024;
-  hipLaunchKernelGGL(k_dft, dim3(gx, (unsigned)c->nbox), dim3(FDTD_BLOCK), 0, s, c->p, kind, c->d_box, c->nfreq,
-                     c->every, c->nsamples, kind == FDTD_KIND_V ? c->tw_v : c->tw_i, step);
+  if (c->recorder)
+    hipLaunchKernelGGL(k_rec, dim3(gx, (unsigned)c->nbox), dim3(FDTD_BLOCK), 0, s, c->p, kind, c->d_box, c->every, c->nsamples, step);
+  else
+    hipLaunchKernelGGL(k_dft, dim3(gx, (unsigned)c->nbox), dim3(FDTD_BLOCK), 0, s, c->p, kind, c->d_box, c->nfreq,
+                       c->every, c->nsamples, kind == FDTD_KIND_V ? c->tw_v : c->tw_i, step);
+}
+
+void launch_rec_dft(const float* rec, long npts, int ns, int nfreq, const double* d_tw, double* d_out, hipStream_t s) {
+  const dim3 grid((unsigned)((npts + FDTD_BLOCK - 1) / FDTD_BLOCK)), block(FDTD_BLOCK);
+  for (int f0 = 0; f0 < nfreq; f0 += 8)
+    hipLaunchKernelGGL((k_rec_dft<8>), grid, block, 0, s, rec, npts, ns, nfreq, f0, d_tw, d_out);
 }
 
 void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_t s) {

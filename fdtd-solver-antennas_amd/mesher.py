@@ -4,7 +4,7 @@ Restates what the reference asks of the external toolkit through
 ``FDTD.AddEdges2Grid(dirs, properties, metal_edge_res)`` and ``mesh.SmoothMeshLines('all', res, 1.4)``
 (antenna_sim/solver_fdtd_openems_fixed.py:193,210,217): [EXT] openEMS automesh / CSXCAD
 SmoothMeshLines.  Their source is not available here, so line positions are NOT pinned against
-them; the invariants are (tests/test_mesher_cpu.py): every hint line is kept, no cell exceeds
+them; the invariants are (tests/test_host_logic_cpu.py::test_mesher_*): every hint line is kept, no cell exceeds
 max_res, neighbouring cells differ by at most `ratio` wherever the hints allow it.
 """
 from __future__ import annotations

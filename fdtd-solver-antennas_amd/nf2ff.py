@@ -3,9 +3,12 @@
 Replaces ``FDTD.CreateNF2FFBox()`` / ``nf2ff.CalcNF2FF(sim_path, f, theta, phi, center=...)``
 (antenna_sim/solver_fdtd_openems_fixed.py:220,296; per-phi loops solver_fdtd_openems_microstrip_3d.py
 :224-225 and _multi_3d.py:620-621).  The external engine dumps time-domain E/H on six faces to HDF5
-and a separate tool DFTs and integrates them; here the DFT runs on the device during time stepping
-(fdtd_add_dft_box) on RAW edge voltages / face currents, and interpolation to the face nodes, the
-equivalent currents and the radiation integral (fdtd_farfield, on the GPU) happen once at the end.
+and a separate tool DFTs and integrates them; here the RAW edge voltages / face currents of the faces
+are either recorded in the time domain in HBM and transformed on the device for any frequency after the
+run (fdtd_set_recorder / fdtd_rec_transform: the reference's semantics, default) or accumulated as a
+running DFT at frequencies fixed beforehand (fdtd_set_dft: constant memory, for very long runs);
+interpolation to the face nodes, the equivalent currents and the radiation integral (fdtd_farfield, on
+the GPU) happen once at the end.
 
 Result attributes mirror what the reference reads from the openEMS result object:
 ``E_norm[f]`` -> (ntheta, nphi), ``Dmax[f]`` (fixed.py:304-305) and ``E_theta, E_phi, P_rad, Prad``
@@ -65,14 +68,18 @@ class NF2FFBox:
     def register(self, engine) -> List[int]:
         return [engine.add_dft_box(r.kind, r.comp, r.lo, r.hi) for r in self.requests]
 
-    def collect(self, engine, ids: List[int]) -> List[np.ndarray]:
+    def collect(self, engine, ids: List[int], tw_v=None, tw_i=None) -> List[np.ndarray]:
         """Per request a complex array [nfreq][nk][nj][ni] covering the whole request box, zero where
-        this slab owns nothing (sum over ranks = complete box)."""
+        this slab owns nothing (sum over ranks = complete box).  With twiddle tables (recorder mode) the
+        recorded time-domain samples are transformed on the device for those frequencies."""
         out = []
         for r, bid in zip(self.requests, ids):
             ext = [r.hi[a] - r.lo[a] + 1 for a in range(3)]
-            full = np.zeros((engine.nfreq, ext[2], ext[1], ext[0]), np.complex128)
-            data, lo, hi = engine.get_dft_box(bid)
+            if tw_v is not None:
+                data, lo, hi = engine.rec_transform(bid, tw_v if r.kind == KIND_V else tw_i)
+            else:
+                data, lo, hi = engine.get_dft_box(bid)
+            full = np.zeros((data.shape[0], ext[2], ext[1], ext[0]), np.complex128)
             if data.size:
                 full[:, lo[2] - r.lo[2]:hi[2] - r.lo[2] + 1, lo[1] - r.lo[1]:hi[1] - r.lo[1] + 1,
                      lo[0] - r.lo[0]:hi[0] - r.lo[0] + 1] = data

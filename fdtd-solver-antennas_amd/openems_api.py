@@ -35,11 +35,6 @@ from .nf2ff import calc_nf2ff, NF2FFResult
 
 _AX = {"x": 0, "y": 1, "z": 2, 0: 0, 1: 1, 2: 2}
 
-# Test hook: a library exporting the same C ABI that Run() uses instead of libfdtd_hip.so when the
-# front object was created without lib= (tests/ put the CPU oracle here to drive the reference's own
-# solver files through this module on a GPU-less host).  The product never sets it.
-_default_lib = None
-
 
 def _plain(v):
     if isinstance(v, np.ndarray):
@@ -241,18 +236,29 @@ class nf2ff:
                                       np.asarray(center, float))
 
 
+def nf2ff_comb(f0: float, every: int = 10) -> np.ndarray:
+    """Every `every`-th point of the reference's S11 grid linspace(max(1 GHz, 0.7 f0), 1.3 f0, 201)
+    (solver_fdtd_openems_microstrip.py:408) plus f0 itself: what the NF2FF faces accumulate when the run is too
+    long for time-domain recording and the caller named no frequencies."""
+    f = np.linspace(max(1e9, 0.7 * f0), 1.3 * f0, 201)[::every]
+    return np.unique(np.append(f, f0))
+
+
 class openEMS:
     """FDTD front object.  Backend options beyond the upstream signature are keyword-only:
     n_gpus / rank / world (z-slab decomposition), device, cpml_cells (default: the _N of 'PML_N'),
-    nf2ff_freqs (frequencies recorded on the NF2FF surfaces; default [f0])."""
+    nf2ff_mode: 'auto' (default) records the NF2FF faces in the time domain in HBM when that fits the budget, so
+    that CalcNF2FF can be asked for ANY frequency after the run, as upstream; otherwise / 'dft': running DFT at
+    nf2ff_freqs (default then: a 21-point comb over the reference's S11 band, CalcNF2FF snaps to the nearest)."""
 
     def __init__(self, NrTS=1e9, EndCriteria=1e-5, *, lib=None, device=0, rank=0, world=1, cpml_cells=None,
-                 nf2ff_freqs=None, comm=None, **kw):
+                 nf2ff_freqs=None, nf2ff_mode="auto", comm=None, **kw):
         self.calls_log = _CallLog()
         self.NrTS, self.EndCriteria = NrTS, EndCriteria
         self.calls_log.add("openEMS", NrTS=NrTS, EndCriteria=EndCriteria)
         self._lib, self._device, self._rank, self._world = lib, device, rank, world
         self._cpml_cells, self._nf2ff_freqs, self._comm = cpml_cells, nf2ff_freqs, comm
+        self._nf2ff_mode, self._nf2ff_snap, self._box_cache = nf2ff_mode, False, {}
         self._csx: Optional[ContinuousStructure] = None
         self._bc = ["PEC"] * 6
         self._f0 = self._fc = None
@@ -353,15 +359,22 @@ class openEMS:
         self.calls_log.add("Run", verbose=verbose, cleanup=cleanup)
         if self._csx is None or self._f0 is None:
             raise RuntimeError("SetCSX and SetGaussExcite must be called before Run")
-        lib = self._lib or _default_lib or load_hip_library()
+        lib = self._lib or load_hip_library()
         grid, sc = self._build_scene()
         vox = voxelize(sc, grid)
         bc = BoundarySpec.parse(self._bc, self._cpml_cells)
         freqs = None
         if self._nf2ff is not None:
             freqs = [self._f0] if self._nf2ff_freqs is None else list(self._nf2ff_freqs)
-        self.sim = Simulation(grid, vox, f0=self._f0, fc=self._fc, boundary=bc, nr_ts=int(min(self.NrTS, 2**31 - 2)),
-                              end_criteria=float(self.EndCriteria), nf2ff_freqs=freqs)
+
+        def make(fr):
+            return Simulation(grid, vox, f0=self._f0, fc=self._fc, boundary=bc, nr_ts=int(min(self.NrTS, 2**31 - 2)),
+                              end_criteria=float(self.EndCriteria), nf2ff_freqs=fr, nf2ff_mode=self._nf2ff_mode)
+        self.sim = make(freqs)
+        self._nf2ff_snap, self._box_cache = False, {}
+        if self._nf2ff is not None and self.sim.nf2ff_mode == "dft" and self._nf2ff_freqs is None:
+            self.sim = make(nf2ff_comb(self._f0))     # no time-domain record: a comb, CalcNF2FF snaps to it
+            self._nf2ff_snap = True
         self.sim.build(lib, rank=self._rank, world=self._world, device=self._device)
         if self._comm is not None:
             self._comm.attach(self.sim)
@@ -370,7 +383,10 @@ class openEMS:
         allreduce = self._comm.allreduce if self._comm is not None else None
         self.stats = self.sim.run(verbose=int(verbose or 0), allreduce=allreduce)
         self._u_i = self.sim.port_series(allreduce)
-        self._boxes = self.sim.nf2ff_boxes(allreduce) if self._nf2ff is not None else None
+        self._allreduce = allreduce
+        self._boxes = None
+        if self._nf2ff is not None and self.sim.nf2ff_mode == "dft":
+            self._boxes = self.sim.nf2ff_boxes(allreduce)
         if sim_path and self._rank == 0:
             try:
                 os.makedirs(sim_path, exist_ok=True)
@@ -396,18 +412,27 @@ class openEMS:
         raise KeyError(number)
 
     def _calc_nf2ff(self, freq, theta_deg, phi_deg, radius, center):
-        if self.sim is None or self._boxes is None:
+        if self.sim is None or self._nf2ff is None or self.sim.nf2ff_box is None:
             raise RuntimeError("Run() with an NF2FF box first")
-        rec = self.sim.nf2ff_freqs
-        idx = []
-        for f in freq:
-            k = int(np.argmin(np.abs(rec - f)))
-            if abs(rec[k] - f) > 1e-6 * max(f, 1.0):
-                raise ValueError(f"NF2FF frequency {f:g} Hz was not recorded (recorded: {rec.tolist()}); "
-                                 "pass nf2ff_freqs=[...] to openEMS(...)")
-            idx.append(k)
         lib = self.sim.lib
-        res = calc_nf2ff(lib, self.sim.nf2ff_box, [b[idx] for b in self._boxes], rec[idx], np.deg2rad(theta_deg),
+        if self.sim.nf2ff_mode == "record":
+            # time-domain faces in HBM: transform them for exactly the frequencies asked for (as upstream's nf2ff does
+            # with the dumps); cached, since the 3-D variants call once per phi (microstrip_3d.py:224-225)
+            key = tuple(float(f) for f in freq)
+            if key not in self._box_cache:
+                self._box_cache = {key: self.sim.nf2ff_boxes(self._allreduce, freqs=freq)}
+            boxes, f_used = self._box_cache[key], freq
+        else:
+            rec = self.sim.nf2ff_freqs
+            idx = []
+            for f in freq:
+                k = int(np.argmin(np.abs(rec - f)))
+                if abs(rec[k] - f) > 1e-6 * max(f, 1.0) and not self._nf2ff_snap:
+                    raise ValueError(f"NF2FF frequency {f:g} Hz was not recorded (recorded: {rec.tolist()}); "
+                                     "pass nf2ff_freqs=[...] or nf2ff_mode='record' to openEMS(...)")
+                idx.append(k)
+            boxes, f_used = [b[idx] for b in self._boxes], rec[idx]
+        res = calc_nf2ff(lib, self.sim.nf2ff_box, boxes, f_used, np.deg2rad(theta_deg),
                          np.deg2rad(phi_deg), center, device=self._device)
         out = _NF2FFResults()
         out.theta, out.phi, out.r, out.freq = res.theta, res.phi, radius, res.freq

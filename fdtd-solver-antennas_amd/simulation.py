@@ -7,6 +7,7 @@ libfdtd_hip.so (``lib`` argument = a library exporting include/fdtd_hip.h).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 import numpy as np
@@ -75,7 +76,7 @@ class Simulation:
                  cpml_cells: Optional[int] = None, nr_ts: int = 30000, end_criteria: float = 1e-4,
                  dt: Optional[float] = None, nf2ff_freqs: Optional[Sequence[float]] = None,
                  nf2ff_inset: Optional[int] = None, dft_oversample: float = 4.0, use_classes: bool = True,
-                 device_operator: bool = True):
+                 device_operator: bool = True, nf2ff_mode: str = "dft", rec_budget_bytes: Optional[int] = None):
         self.grid, self.vox = grid, vox
         self.f0, self.fc = float(f0), float(fc)
         self.bc = BoundarySpec.parse(boundary, cpml_cells)
@@ -101,6 +102,7 @@ class Simulation:
         # NF2FF recording
         self.nf2ff_box: Optional[NF2FFBox] = None
         self.nf2ff_freqs = None
+        self.nf2ff_mode, self.rec_bytes, self.nf2ff_fmax = "dft", 0, 0.0
         if nf2ff_freqs is not None:
             self.nf2ff_freqs = np.atleast_1d(np.asarray(nf2ff_freqs, float))
             n = grid.shape
@@ -114,6 +116,16 @@ class Simulation:
             fmax = max(self.f0 + self.fc, float(np.max(self.nf2ff_freqs)))
             self.dft_every = max(1, int(np.floor(1.0 / (2.0 * fmax * dft_oversample * self.dt))))
             self.dft_nsamples = self.nr_ts // self.dft_every + 1
+            # "record": the faces keep float32 time-domain samples in HBM and any frequency <= fmax can be asked for
+            # after the run (what CalcNF2FF does with the engine's dumps); "dft": running sums at nf2ff_freqs only
+            # (constant memory).  "auto" records when the samples fit the budget (default 32 GiB of 288 GB per GPU).
+            if nf2ff_mode not in ("dft", "record", "auto"):
+                raise ValueError("nf2ff_mode must be 'dft', 'record' or 'auto'")
+            self.rec_bytes = 4 * self.dft_nsamples * sum(
+                int(np.prod([r.hi[a] - r.lo[a] + 1 for a in range(3)])) for r in self.nf2ff_box.requests)
+            budget = int(os.environ.get("FDTD_REC_BUDGET_BYTES", 32 << 30)) if rec_budget_bytes is None else int(rec_budget_bytes)
+            self.nf2ff_mode = nf2ff_mode if nf2ff_mode != "auto" else ("record" if self.rec_bytes <= budget else "dft")
+            self.nf2ff_fmax = fmax
         self.engine: Optional[Engine] = None
         self.lib = None
         self.external_transport = None     # distributed.SlabComm when halos travel through the host
@@ -167,10 +179,18 @@ class Simulation:
             iid = e.add_probe(KIND_I, p.i_idx, p.i_comp, p.i_w)
             self._port_probe_ids.append((uid, iid))
         if self.nf2ff_box is not None:
-            tw_v = dft_twiddles(self.nf2ff_freqs, self.dt, self.dft_every, self.dft_nsamples, 0.0)
-            tw_i = dft_twiddles(self.nf2ff_freqs, self.dt, self.dft_every, self.dft_nsamples, 0.5)
-            e.set_dft(self.dft_every, tw_v, tw_i)
-            self._nf_ids = self.nf2ff_box.register(e)
+            if self.nf2ff_mode == "record":
+                try:
+                    e.set_recorder(self.dft_every, self.dft_nsamples)
+                    self._nf_ids = self.nf2ff_box.register(e)
+                except _capi.FdtdError as err:
+                    raise _capi.FdtdError(f"{err} — time-domain NF2FF recording needs {self.rec_bytes / 2**30:.1f} GiB; "
+                                          "use nf2ff_mode='dft'") from err
+            else:
+                tw_v = dft_twiddles(self.nf2ff_freqs, self.dt, self.dft_every, self.dft_nsamples, 0.0)
+                tw_i = dft_twiddles(self.nf2ff_freqs, self.dt, self.dft_every, self.dft_nsamples, 0.5)
+                e.set_dft(self.dft_every, tw_v, tw_i)
+                self._nf_ids = self.nf2ff_box.register(e)
         self.engine, self.lib = e, lib
         self.rank, self.world, self.device = rank, world, device
         return e
@@ -225,8 +245,20 @@ class Simulation:
             out.append((u, i))
         return out
 
-    def nf2ff_boxes(self, allreduce=None):
-        boxes = self.nf2ff_box.collect(self.engine, self._nf_ids)
+    def nf2ff_boxes(self, allreduce=None, freqs=None):
+        """Frequency-domain surface data [nfreq][k][j][i] per recording request.  `freqs`: recorder mode only — any
+        frequencies up to nf2ff_fmax (default: nf2ff_freqs); in dft mode the recorded set is returned."""
+        if self.nf2ff_mode == "record":
+            f = self.nf2ff_freqs if freqs is None else np.atleast_1d(np.asarray(freqs, float))
+            if f.size and float(np.max(f)) > self.nf2ff_fmax * (1 + 1e-9):
+                raise ValueError(f"NF2FF frequency {float(np.max(f)):g} Hz is above the recorder's band ({self.nf2ff_fmax:g} Hz)")
+            tw_v = dft_twiddles(f, self.dt, self.dft_every, self.dft_nsamples, 0.0)
+            tw_i = dft_twiddles(f, self.dt, self.dft_every, self.dft_nsamples, 0.5)
+            boxes = self.nf2ff_box.collect(self.engine, self._nf_ids, tw_v, tw_i)
+        else:
+            if freqs is not None:
+                raise ValueError("dft mode records nf2ff_freqs only")
+            boxes = self.nf2ff_box.collect(self.engine, self._nf_ids)
         if allreduce is not None:
             boxes = [allreduce(b) for b in boxes]
         scale = self.dt * self.dft_every

@@ -84,6 +84,9 @@ class FDTDPrepared:
     port: Optional[object] = None           # first port (upstream forgot to keep it: microstrip.py:393)
     ports: List[object] = field(default_factory=list)
     variant: str = "fixed"
+    # far field at the S11 resonance instead of frequency_hz: None = as the reference's variant does (only the
+    # microstrip variant searches, microstrip.py:407-433; fixed.py:289 and the 3-D variants use frequency_hz)
+    pattern_at_resonance: Optional[bool] = None
 
 
 @dataclass
@@ -99,7 +102,8 @@ class FDTDResult:
     freq: Optional[np.ndarray] = None
     s11: Optional[np.ndarray] = None        # complex, first port
     s11_dB: Optional[np.ndarray] = None
-    f_res: Optional[float] = None
+    f_res: Optional[float] = None           # resonance pick of microstrip.py:414-423 (frequency_hz if no dip below -10 dB)
+    f_pattern: Optional[float] = None       # frequency the far field was evaluated at
     Dmax: Optional[float] = None
     port_u: Optional[np.ndarray] = None
     port_i: Optional[np.ndarray] = None
@@ -116,12 +120,12 @@ OpenEMSProbe, OpenEMSPrepared, OpenEMSResult = FDTDProbe, FDTDPrepared, FDTDResu
 # ---------------------------------------------------------------------------------------------------
 def _load(dll_dir: Optional[str], backend: Optional[dict] = None):
     """libfdtd_hip.so from dll_dir (None = in-tree build); raises if missing — no CPU fallback.
-    `_engine_lib` in the backend options is the test hook through which tests/ inject another library
-    exporting the same C ABI (the CPU oracle, as the checker)."""
-    if backend is not None and backend.get("_engine_lib") is not None:
-        return backend.pop("_engine_lib")
+    An explicit `lib=` backend option is an already loaded library exporting include/fdtd_hip.h (a build kept
+    elsewhere; tests/ pass the CPU oracle, the checker, this way) — the same keyword openems_api.openEMS takes."""
+    if backend is not None and backend.get("lib") is not None:
+        return backend.pop("lib")
     if backend is not None:
-        backend.pop("_engine_lib", None)
+        backend.pop("lib", None)
     return _capi.load_hip_library(dll_dir or None)
 
 
@@ -561,15 +565,22 @@ def run_prepared_hip(prepared: FDTDPrepared, *, frequency_hz: float, verbose: in
         th = np.asarray(prepared.theta, dtype=float)
         ph = np.asarray(prepared.phi, dtype=float)
         th_deg, ph_deg = (np.rad2deg(th), np.rad2deg(ph)) if legacy else (th, ph)
-        res = nf.CalcNF2FF(sim_path, frequency_hz, th_deg, ph_deg, center=prepared.nf_center)
+        # port parameters first (microstrip.py:407-426): the resonance they give is where the microstrip variant
+        # takes its far field (:433)
+        s11_out = s11_from_port(prepared.port, sim_path, frequency_hz) if prepared.port is not None else None
+        at_res = prepared.pattern_at_resonance
+        if at_res is None:
+            at_res = prepared.variant == "microstrip"
+        f_eval = float(s11_out[3]) if (at_res and s11_out is not None) else float(frequency_hz)
+        res = nf.CalcNF2FF(sim_path, f_eval, th_deg, ph_deg, center=prepared.nf_center)
         E = np.asarray(res.E_norm[0])
         Dmax = float(np.asarray(res.Dmax)[0])
         intensity = pattern_to_dBi(E, Dmax, prepared.variant)
         out = FDTDResult(True, f"fdtd-hip FDTD completed ({prepared.variant})", theta=np.deg2rad(th_deg),
                          phi=np.deg2rad(ph_deg), intensity=intensity, sim_path=sim_path, is_dBi=True, Dmax=Dmax)
-        if prepared.port is not None:
-            f, s11, s11_dB, f_res = s11_from_port(prepared.port, sim_path, frequency_hz)
-            out.freq, out.s11, out.s11_dB, out.f_res = f, s11, s11_dB, f_res
+        out.f_pattern = float(np.atleast_1d(res.freq)[0])     # == f_eval unless a dft-mode comb snapped it
+        if s11_out is not None:
+            out.freq, out.s11, out.s11_dB, out.f_res = s11_out
             out.port_u = prepared.port.u_data.ui_val[0]
             out.port_i = prepared.port.i_data.ui_val[0]
             out.dt = fdtd.sim.dt

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FDTD_ABI_VERSION 1
+#define FDTD_ABI_VERSION 2
 
 enum {
   FDTD_OK = 0,
@@ -182,6 +182,19 @@ int fdtd_add_dft_box(fdtd_ctx* ctx, int kind, int comp, const int32_t lo[3], con
 /* Returns the part of the box inside this slab: lo_own/hi_own (GLOBAL indices; hi<lo if empty) and
  * out[nfreq][kk][jj][ii][2].  out may be NULL to query the extent only. */
 int fdtd_get_dft_box(fdtd_ctx* ctx, int id, double* out, int32_t lo_own[3], int32_t hi_own[3]);
+
+/* Time-domain recording of the same boxes — the alternative to fdtd_set_dft (call ONE of the two before the first
+ * fdtd_add_dft_box).  This is what the reference's engine does with an NF2FF box: it dumps the surface fields in the time
+ * domain and nf2ff.CalcNF2FF(sim_path, f, ...) transforms them to whatever frequency the caller asks for AFTER the run
+ * (solver_fdtd_openems_fixed.py:220,296) — e.g. the S11 resonance, which is only known then
+ * (solver_fdtd_openems_microstrip.py:407-433).  Every `every` steps the raw float32 samples of each box go to device
+ * memory, [nsamples][npts] per box (sized for 288 GB of HBM; FDTD_E_NOMEM from fdtd_add_dft_box = use fdtd_set_dft). */
+int fdtd_set_recorder(fdtd_ctx* ctx, int every, int nsamples);
+/* out[nfreq][kk][jj][ii][2] = sum over the samples s recorded so far, in order, of sample_s * tw[s][f] (on the device,
+ * float64 fma chain: bit for bit what the running DFT of fdtd_set_dft accumulates for the same tw).
+ * tw: [nsamples][nfreq][2] for THIS box's field kind.  out may be NULL to query the owned extent only. */
+int fdtd_rec_transform(fdtd_ctx* ctx, int id, int nfreq, const double* tw, double* out,
+                       int32_t lo_own[3], int32_t hi_own[3]);
 
 /* ---- time stepping ------------------------------------------------------------------------ */
 /* Run nsteps full leapfrog steps (halo exchange inside when world > 1 and a communicator is set).

@@ -49,7 +49,8 @@ typedef struct {
   int32_t lo[3], hi[3];     /* global box */
   int32_t olo[3], ohi[3];   /* owned part (global indices), empty if ohi<olo */
   size_t npts;
-  double* acc;              /* [nfreq][npts][2] */
+  double* acc;              /* running DFT: [nfreq][npts][2] */
+  float* rec;               /* recorder: [nsamples][npts] raw samples */
 } dftbox_t;
 
 struct fdtd_ctx {
@@ -77,6 +78,7 @@ struct fdtd_ctx {
   int nprobe; probe_t probe[MAX_PROBES];
   int nbox; dftbox_t box[MAX_BOXES];
   int nfreq, every, nsamples; double *tw_v, *tw_i;
+  int recorder;             /* 1: boxes keep time-domain samples (fdtd_set_recorder) instead of running DFT sums */
   int64_t step;
   char err[512];
 };
@@ -131,7 +133,7 @@ void fdtd_destroy(fdtd_ctx* c) {
   for (int f = 0; f < 6; ++f) { free(c->mur_st[f][0]); free(c->mur_st[f][1]); }
   free(c->sig); free(c->src_off); free(c->src_comp); free(c->src_amp); free(c->src_delay);
   for (int p = 0; p < c->nprobe; ++p) { free(c->probe[p].off); free(c->probe[p].comp); free(c->probe[p].w); free(c->probe[p].series); }
-  for (int b = 0; b < c->nbox; ++b) free(c->box[b].acc);
+  for (int b = 0; b < c->nbox; ++b) { free(c->box[b].acc); free(c->box[b].rec); }
   free(c->tw_v); free(c->tw_i);
   free(c);
 }
@@ -413,7 +415,11 @@ int fdtd_add_probe(fdtd_ctx* c, int kind, int n, const int64_t* idx, const int8_
   p->series = calloc(c->d.max_steps > 0 ? c->d.max_steps : 1, sizeof(double));
   for (int e = 0; e < n; ++e) {
     int64_t l = to_local(c, idx[e]);
-    if (l == -2 || comp[e] < 0 || comp[e] > 2) return fail(c, FDTD_E_ARG, "probe edge %d out of grid", e);
+    if (l == -2 || comp[e] < 0 || comp[e] > 2) {
+      free(p->off); free(p->comp); free(p->w); free(p->series);
+      memset(p, 0, sizeof(*p));
+      return fail(c, FDTD_E_ARG, "probe edge %d out of grid", e);
+    }
     if (l < 0) continue;
     p->off[p->n] = l; p->comp[p->n] = comp[e]; p->w[p->n] = w[e]; p->n++;
   }
@@ -441,9 +447,19 @@ int fdtd_set_dft(fdtd_ctx* c, int nfreq, int every, int nsamples, const double* 
   return FDTD_OK;
 }
 
+/* Time-domain recording of the boxes: [EXT] what openEMS's NF2FF box dumps (CreateNF2FFBox, solver_fdtd_openems_fixed.py:220)
+ * for nf2ff.CalcNF2FF to transform at any frequency afterwards (:296; the S11 resonance of microstrip.py:407-433). */
+int fdtd_set_recorder(fdtd_ctx* c, int every, int nsamples) {
+  if (!c || every < 1 || nsamples < 1) return fail(c, FDTD_E_ARG, "bad recorder setup");
+  if (c->nbox) return fail(c, FDTD_E_STATE, "set_recorder must precede add_dft_box");
+  free(c->tw_v); free(c->tw_i); c->tw_v = c->tw_i = NULL;
+  c->nfreq = 0; c->recorder = 1; c->every = every; c->nsamples = nsamples;
+  return FDTD_OK;
+}
+
 int fdtd_add_dft_box(fdtd_ctx* c, int kind, int comp, const int32_t lo[3], const int32_t hi[3], int* id_out) {
   if (!c || !lo || !hi || comp < 0 || comp > 2 || (kind != 0 && kind != 1)) return fail(c, FDTD_E_ARG, "bad dft box");
-  if (!c->nfreq) return fail(c, FDTD_E_STATE, "set_dft first");
+  if (!c->nfreq && !c->recorder) return fail(c, FDTD_E_STATE, "set_dft or set_recorder first");
   if (c->nbox >= MAX_BOXES) return fail(c, FDTD_E_NOMEM, "too many dft boxes");
   const int dims[3] = {c->d.nx, c->d.ny, c->d.nz};
   for (int a = 0; a < 3; ++a)
@@ -456,7 +472,12 @@ int fdtd_add_dft_box(fdtd_ctx* c, int kind, int comp, const int32_t lo[3], const
   if (b->ohi[2] > c->d.k0 + c->d.nk - 1) b->ohi[2] = c->d.k0 + c->d.nk - 1;
   b->npts = b->ohi[2] < b->olo[2] ? 0 :
       (size_t)(b->ohi[0] - b->olo[0] + 1) * (b->ohi[1] - b->olo[1] + 1) * (b->ohi[2] - b->olo[2] + 1);
-  b->acc = b->npts ? calloc(b->npts * c->nfreq * 2, sizeof(double)) : NULL;
+  if (c->recorder) {
+    b->rec = b->npts ? calloc(b->npts * (size_t)c->nsamples, sizeof(float)) : NULL;
+    if (b->npts && !b->rec) return fail(c, FDTD_E_NOMEM, "recorder box: %zu samples", b->npts * (size_t)c->nsamples);
+  } else {
+    b->acc = b->npts ? calloc(b->npts * c->nfreq * 2, sizeof(double)) : NULL;
+  }
   if (id_out) *id_out = c->nbox;
   c->nbox++;
   return FDTD_OK;
@@ -466,7 +487,38 @@ int fdtd_get_dft_box(fdtd_ctx* c, int id, double* out, int32_t lo_own[3], int32_
   if (!c || id < 0 || id >= c->nbox) return fail(c, FDTD_E_ARG, "bad dft box id");
   dftbox_t* b = &c->box[id];
   for (int a = 0; a < 3; ++a) { if (lo_own) lo_own[a] = b->olo[a]; if (hi_own) hi_own[a] = b->ohi[a]; }
+  if (out && c->recorder) return fail(c, FDTD_E_STATE, "recorder mode: use fdtd_rec_transform");
   if (out && b->npts) memcpy(out, b->acc, b->npts * c->nfreq * 2 * sizeof(double));
+  return FDTD_OK;
+}
+
+/* samples of `kind` taken so far: steps 0, every, 2*every, ... of the half-steps already done */
+static int64_t rec_count(const fdtd_ctx* c) {
+  int64_t n = (c->step + c->every - 1) / c->every;
+  return n < c->nsamples ? n : c->nsamples;
+}
+
+int fdtd_rec_transform(fdtd_ctx* c, int id, int nfreq, const double* tw, double* out, int32_t lo_own[3], int32_t hi_own[3]) {
+  if (!c || id < 0 || id >= c->nbox) return fail(c, FDTD_E_ARG, "bad box id");
+  if (!c->recorder) return fail(c, FDTD_E_STATE, "not in recorder mode");
+  dftbox_t* b = &c->box[id];
+  for (int a = 0; a < 3; ++a) { if (lo_own) lo_own[a] = b->olo[a]; if (hi_own) hi_own[a] = b->ohi[a]; }
+  if (!out || !b->npts) return FDTD_OK;
+  if (nfreq < 1 || !tw) return fail(c, FDTD_E_ARG, "bad transform");
+  const int64_t ns = rec_count(c);
+  for (int f = 0; f < nfreq; ++f) {
+    double* o = out + (size_t)f * b->npts * 2;
+#pragma omp parallel for schedule(static)
+    for (int64_t pt = 0; pt < (int64_t)b->npts; ++pt) {
+      double ar = 0.0, ai = 0.0;
+      for (int64_t s_ = 0; s_ < ns; ++s_) {
+        const double v = (double)b->rec[(size_t)s_ * b->npts + pt];
+        ar = fma(v, tw[((size_t)s_ * nfreq + f) * 2], ar);
+        ai = fma(v, tw[((size_t)s_ * nfreq + f) * 2 + 1], ai);
+      }
+      o[2 * pt] = ar; o[2 * pt + 1] = ai;
+    }
+  }
   return FDTD_OK;
 }
 
@@ -625,6 +677,20 @@ static void sample(fdtd_ctx* c, int kind) {
       for (int e = 0; e < pr->n; ++e) s = fma((double)pr->w[e], (double)F[pr->comp[e]][pr->off[e]], s);
       pr->series[c->step] = s;
     }
+  if (c->recorder && c->step % c->every == 0 && c->step / c->every < c->nsamples) {
+    const int64_t smp = c->step / c->every;
+    for (int b = 0; b < c->nbox; ++b) {
+      dftbox_t* bx = &c->box[b];
+      if (bx->kind != kind || !bx->npts) continue;
+      const float* fld = F[bx->comp];
+      const int ni = bx->ohi[0] - bx->olo[0] + 1, nj = bx->ohi[1] - bx->olo[1] + 1, nkk = bx->ohi[2] - bx->olo[2] + 1;
+      float* dst = bx->rec + (size_t)smp * bx->npts;
+      for (int kk = 0; kk < nkk; ++kk)
+        for (int jj = 0; jj < nj; ++jj)
+          memcpy(dst + ((size_t)kk * nj + jj) * ni,
+                 fld + ((size_t)(bx->olo[2] - c->d.k0 + kk) * c->d.ny + bx->olo[1] + jj) * c->d.nx + bx->olo[0], (size_t)ni * sizeof(float));
+    }
+  }
   if (c->nfreq && c->step % c->every == 0) {
     int64_t smp = c->step / c->every;
     if (smp < c->nsamples) {

@@ -110,12 +110,12 @@ def test_rotated_box_voxelisation():
 
 def test_fixed_scene_end_to_end_with_oracle_engine(oracle_lib, tmp_path):
     """PatchAntennaParams in -> OpenEMSResult-shaped object out, through the plugin surface, with the
-    oracle standing in for the GPU library (test hook `_engine_lib`).  Physics bands:
+    oracle standing in for the GPU library (test hook `lib`).  Physics bands:
     this variant puts W = 37.6 mm on the resonant axis, so the S11 dip sits near 1.9 GHz."""
     s = pkg("solver_fdtd_hip")
     P = pkg("params").PatchAntennaParams
     p = P.from_user_units(frequency_ghz=2.45, er=4.3, h_mm=1.6, loss_tangent=0.02)
-    prep = s.prepare_hip_patch_fixed(p, work_dir=str(tmp_path / "run"), _engine_lib=oracle_lib)
+    prep = s.prepare_hip_patch_fixed(p, work_dir=str(tmp_path / "run"), lib=oracle_lib)
     assert prep.ok, prep.message
     prep.FDTD.NrTS = 9000
     r = s.run_prepared_hip(prep, frequency_hz=2.45e9, verbose=0)

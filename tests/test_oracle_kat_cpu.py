@@ -184,6 +184,6 @@ def test_lossy_medium_decays_and_linearity(oracle_lib):
         # conduction (kappa = 0.5 S/m, eps0/kappa = 18 ps) kills the electric part; the magnetic part only diffuses
         assert v1 < 1e-2 * v0 and i1 < i0
         outs.append(e.fields())
-    assert np.array_equal(outs[1], np.float32(-2.0) * outs[0])  # power-of-two scaling commutes exactly with every float op
-    rel = 0.0
-    assert rel < 1e-5
+    # power-of-two scaling commutes exactly with every float op: linearity holds bit for bit, not to a tolerance
+    assert np.abs(outs[0]).max() > 0
+    assert np.array_equal(outs[1], np.float32(-2.0) * outs[0])

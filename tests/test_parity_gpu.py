@@ -232,7 +232,7 @@ def test_plugin_path_s11_and_patterns_gpu_vs_oracle(hip_lib, oracle_lib, tmp_pat
     res = []
     for lib, tag in ((hip_lib, "gpu"), (oracle_lib, "cpu")):
         prep = s.prepare_hip_microstrip_patch_3d(p, feed_direction=s.FeedDirection.NEG_X, boundary="PML_8", theta_step_deg=4.0,
-                                                 phi_step_deg=15.0, mesh_quality=1, work_dir=str(tmp_path / tag), _engine_lib=lib)
+                                                 phi_step_deg=15.0, mesh_quality=1, work_dir=str(tmp_path / tag), lib=lib)
         assert prep.ok, prep.message
         prep.FDTD.NrTS = 2500
         r = s.run_prepared_hip(prep, frequency_hz=5.8e9, verbose=0)
