@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload NS|C2|C3|C4|C5]
 
-One bench "step" = `--ts-per-step` (default 100) full FDTD timesteps (E half-step + H half-step incl.
+One bench "step" = `--ts-per-step` (default 500, so the driver's `--steps 20` times BASELINE's 10 000 timesteps) full FDTD timesteps (E half-step + H half-step incl.
 CPML, source, port probes and NF2FF running-DFT surfaces) of the named BASELINE workload; default
 workload is the north-star 300x300x60 patch-on-FR-4 grid with 10-cell CPML, fp32.  Inputs are
 resident in HBM before the timed region.  For N > 1 (launched by torch.distributed.run, one rank
@@ -11,9 +11,11 @@ per GPU) the SAME global grid is z-slab decomposed over the ranks (strong scalin
 states the target); the halo planes travel inside libfdtd_hip.so — P2P mailboxes written by the update
 kernels over xGMI by default, RCCL send/recv on a second stream with `--halo rccl`.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event kernel
-durations of the dominant kernel vs 36 algorithmic bytes per cell per half-step) and, at N = 1,
-`cpu_baseline` (the oracle, test infrastructure, timed on the host cores as a reported non-target).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (begin-to-end durations of the
+dominant kernel, from start / stop events carried by every main launch = the interval a rocprofv3 kernel trace reports,
+vs 36 algorithmic bytes per cell per half-step), at N = 1 `roofline_hbm_resident` (the same measurement on C3,
+400x400x80, whose fields do not fit the 256 MiB Infinity Cache) and `cpu_baseline` (the oracle, test infrastructure,
+timed on the host cores as a reported non-target).
 """
 import argparse
 import ctypes
@@ -40,13 +42,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="NS")
-    ap.add_argument("--ts-per-step", type=int, default=100)
+    ap.add_argument("--ts-per-step", type=int, default=500)
     ap.add_argument("--cpml-cells", type=int, default=10)
     ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "fused", "tile", "march"])
     ap.add_argument("--halo", default="auto", choices=["auto", "p2p", "rccl", "host"],
                     help="N > 1: halo transport (auto = P2P mailbox, then RCCL, then host copies)")
     ap.add_argument("--raw-operator", action="store_true", help="stream 12 coefficient arrays instead of class bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-point", action="store_true", help="skip the C3 (HBM-resident) roofline block")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle timesteps for the cpu_baseline leg (0 = auto)")
     args = ap.parse_args()
 
@@ -63,7 +66,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # launched by torch.distributed.run: bring the process group up also at world 1, so that the one-GPU box exercises the
+    # same RCCL ("nccl") bootstrap the N-GPU runs depend on
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("FDTD_BENCH_DIST_BACKEND", "nccl")
         if backend == "nccl":
@@ -112,7 +118,7 @@ def main():
     for _ in range(args.steps):
         run_steps(tps)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = local_elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -122,39 +128,45 @@ def main():
     timesteps = args.steps * tps
     value = ncells * timesteps / elapsed / 1e6
 
-    # roofline of the dominant kernel (E half-step == H half-step in algorithmic bytes): HIP events on
-    # the engine's own stream around every main-kernel launch, over a second pass of the same length; the
-    # interval an event pair measures with NOTHING between (the event packets' own time, calibrated in the same
-    # call) is subtracted, which is what makes the figure agree with rocprofv3's kernel durations.
+    # roofline of the dominant kernel (E half-step == H half-step in algorithmic bytes): a second pass of the same
+    # length in which every main launch carries start / stop events (hipExtLaunchKernelGGL) = the dispatch's begin
+    # and end timestamps, the interval a rocprofv3 kernel trace reports; nothing is subtracted.
     if sim.external_transport is not None:      # host transport: no in-library step loop to profile
         prof = capi.FdtdProfile(ms_total=elapsed * 1e3, ms_update_e=float("nan"), ms_update_h=float("nan"), steps=timesteps)
     else:
         prof = eng.run_profiled(min(timesteps, 2000))
-    own_cells = eng.nk * eng.ny * eng.nx
-    algo_bytes = ALGO_BYTES_PER_CELL_HALFSTEP * own_cells
-    ms_e, ms_h = prof.ms_update_e, prof.ms_update_h
-    if prof.fused:      # one launch does both half-steps: 72 algorithmic bytes per cell per launch
-        dom, ms_dom, algo_bytes = "step_fused", ms_e, 2 * algo_bytes
-    else:
-        dom = "update_E" if ms_e >= ms_h else "update_H"
-        ms_dom = max(ms_e, ms_h)
-    if ms_dom == ms_dom and ms_dom > 0:
-        achieved = algo_bytes / (ms_dom * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload, dom, world),
-                    "kernel": dom, "ms_update_E": round(ms_e, 5), "ms_update_H": round(ms_h, 5),
-                    "algorithmic_bytes_per_launch": algo_bytes,
-                    "ms_event_overhead_subtracted": round(prof.ms_event_overhead, 5),
-                    "ms_per_timestep_profiled": round(prof.ms_total / prof.steps, 5)}
-    else:               # host halo transport: kernels are launched one half-step at a time, nothing to profile
-        roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                    "traffic": None, "kernel": dom, "algorithmic_bytes_per_launch": algo_bytes}
+    roofline = roofline_block(args.workload, eng, prof, world, sim.external_transport is not None)
     finite = bool(np.isfinite(eng.get_field(0, 2)).all())
+    # L2 norm of the first port's voltage series over every timestep stepped so far (rank-summed): identical for every
+    # N and every halo transport, since the decomposed run is bit-identical to the single-slab run
+    u0 = sim.port_series(comm.allreduce if world > 1 else None)[0][0]
+    port_u_l2 = float(np.sqrt(np.sum(np.asarray(u0, float) ** 2)))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(capi, simm, w, vox, args)
 
+    # N > 1: what shows that the ranks really stepped ONE coupled grid — every rank answers (ranks_seen), the transport
+    # they agreed on, the size of the RCCL communicator when that is the transport, each rank's own time per step, and
+    # max|V| of every slab (the port sits in one slab: any other slab is non-zero only through its halos)
+    coupling = None
+    if world > 1:
+        seen = comm.allreduce(np.array([1.0]))
+        vmax = max(float(np.abs(eng.get_field(0, c)).max()) for c in range(3))
+        rec = [None] * world
+        dist.all_gather_object(rec, {"rank": rank, "ms_per_step": round(local_elapsed / args.steps * 1e3, 4),
+                                     "slab_planes": int(eng.nk), "slab_max_abs_V": vmax,
+                                     "ms_halo_host_exchange": round(getattr(comm, "ms_exchange", 0.0) / max(args.steps + args.warmup, 1), 4),
+                                     "rccl_nranks": eng.comm_nranks()})
+        coupling = {"ranks_seen": int(round(float(seen[0]))), "transport_used": comm.transport_used,
+                    "rccl_nranks": rec[0]["rccl_nranks"], "per_rank": rec,
+                    "all_slabs_excited": bool(all(r["slab_max_abs_V"] > 0 for r in rec))}
+    operator_form, steps_total = sim.operator_form, int(eng.step)
+    hbm_point = None
+    if rank == 0 and world == 1 and not args.no_hbm_point and args.workload != "C3":
+        del eng
+        sim.engine = None                     # frees the NS context before the C3 one is built
+        hbm_point = hbm_resident_point(capi, wl, sc, simm, hip, args)
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -166,16 +178,80 @@ def main():
             "config": {"workload": f"{args.workload}: {w.grid.shape[0]}x{w.grid.shape[1]}x{w.grid.shape[2]} "
                                    f"{SCENES.get(args.workload, 'patch')}, CPML-{args.cpml_cells}, "
                                    f"{len(vox.ports)} lumped port(s), NF2FF DFT surfaces",
-                       "cells": ncells, "timesteps_per_step": tps, "operator": sim.operator_form,
+                       "cells": ncells, "timesteps_per_step": tps, "operator": operator_form,
                        "parallelism": f"z-slab x{world}, halo transport {comm.transport_used}" if world > 1 else "single GPU",
-                       "fields_finite": finite},
+                       "fields_finite": finite, "port_u_l2": port_u_l2, "timesteps_total": steps_total},
             "roofline": roofline,
         }
+        if hbm_point is not None:
+            out["roofline_hbm_resident"] = hbm_point
+        if coupling is not None:
+            out["multi_gpu"] = coupling
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        if world == 1:
+            dist.barrier()
         dist.destroy_process_group()
+
+
+def working_set_bytes(eng):
+    """Six field arrays + class bytes of the slab (what the two sweeps stream every timestep)."""
+    return int(eng.nk) * int(eng.ny) * int(eng.nx) * (6 * 4 + 1)
+
+
+def roofline_block(workload, eng, prof, world, host_transport):
+    own_cells = eng.nk * eng.ny * eng.nx
+    algo_bytes = ALGO_BYTES_PER_CELL_HALFSTEP * own_cells
+    ms_e, ms_h = prof.ms_update_e, prof.ms_update_h
+    if prof.fused:      # one launch does both half-steps: 72 algorithmic bytes per cell per launch
+        dom, ms_dom, algo_bytes = "step_fused", ms_e, 2 * algo_bytes
+    else:
+        dom = "update_E" if ms_e >= ms_h else "update_H"
+        ms_dom = max(ms_e, ms_h)
+    if host_transport or not (ms_dom == ms_dom and ms_dom > 0):
+        # host halo transport: kernels are launched one half-step at a time, nothing to profile
+        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "kernel": dom, "algorithmic_bytes_per_launch": algo_bytes}
+    achieved = algo_bytes / (ms_dom * 1e-3) / 1e9
+    ms_ts = prof.ms_total / prof.steps
+    traffic, source = pmc_traffic(workload, dom, world)
+    ws = working_set_bytes(eng)
+    out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+           "traffic_source": source, "kernel": dom, "ms_update_E": round(ms_e, 5), "ms_update_H": round(ms_h, 5),
+           "algorithmic_bytes_per_launch": algo_bytes,
+           "kernel_timing": "dispatch begin/end timestamps (start/stop events on every main launch), nothing subtracted",
+           "ms_per_timestep_profiled": round(ms_ts, 5),
+           # the 256 MiB Infinity Cache holds the whole working set of the smaller grids: their 'HBM' rate is a cache rate
+           "resident": "infinity-cache" if ws < (240 << 20) else "hbm", "working_set_bytes": ws}
+    if not prof.fused and world == 1:
+        # the two main launches of a timestep cannot take longer than the timestep, and leave only launch gaps + the
+        # occasional DFT launch: a figure outside this band means the kernel timing is broken, not the kernel
+        ratio = (ms_e + ms_h) / ms_ts
+        out["kernels_over_timestep"] = round(ratio, 4)
+        assert 0.80 < ratio <= 1.02, f"kernel durations {ms_e:.5f} + {ms_h:.5f} ms do not add up to the timestep {ms_ts:.5f} ms"
+    return out
+
+
+def hbm_resident_point(capi, wl, sc, simm, hip, args, name="C3", steps=300):
+    """The same roofline measurement on C3 (400x400x80): 307 MB of fields do not fit the 256 MiB Infinity Cache, so this
+    is the HBM-resident point of the chip for this kernel (the north-star grid is cache-resident)."""
+    w = wl.baseline_workload(name)
+    vox = sc.voxelize(w.scene, w.grid)
+    sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=args.cpml_cells, nr_ts=4 * steps + 64,
+                          nf2ff_freqs=[w.f0], use_classes=not args.raw_operator)
+    eng = sim.build(hip)
+    eng.run(steps // 2)
+    t0 = time.perf_counter()
+    eng.run(steps)
+    dt = time.perf_counter() - t0
+    prof = eng.run_profiled(steps)
+    blk = roofline_block(name, eng, prof, 1, False)
+    blk["workload"] = f"{name}: {w.grid.shape[0]}x{w.grid.shape[1]}x{w.grid.shape[2]} fixed scene, CPML-{args.cpml_cells}, {steps} timesteps"
+    blk["value_mcells_s"] = round(w.grid.ncells * steps / dt / 1e6, 1)
+    return blk
 
 
 def pmc_traffic(workload, kernel, world):
@@ -185,18 +261,19 @@ def pmc_traffic(workload, kernel, world):
     null unless a committed measurement exists for this workload at N = 1."""
     import glob
     if world != 1:
-        return None
+        return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{workload}_*.json")))
     if not files:
-        return None
+        return None, None
     try:
         data = json.load(open(files[-1]))["per_launch_traffic"]
         for name, rec in data.items():
             if kernel.replace("update_", "k_update_").replace("step_fused", "k_step_fused") in name:
-                return round(rec["total_bytes"])
+                return round(rec["total_bytes"]), ("committed rocprofv3 --pmc passes, not measured in this run: "
+                                                   + os.path.relpath(files[-1], ROOT))
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return None, None
 
 
 def usable_cores() -> int:

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "fdtd_operator_form", "fdtd_get_operator", "fdtd_set_cpml",
     "fdtd_set_mur", "fdtd_set_signal", "fdtd_add_source", "fdtd_add_probe", "fdtd_get_probe",
     "fdtd_set_dft", "fdtd_add_dft_box", "fdtd_get_dft_box", "fdtd_set_recorder", "fdtd_rec_transform", "fdtd_run", "fdtd_run_profiled",
-    "fdtd_get_step", "fdtd_energy", "fdtd_p2p_export", "fdtd_p2p_attach", "fdtd_p2p_selftest", "fdtd_p2p_detach", "fdtd_comm_unique_id", "fdtd_comm_init", "fdtd_link", "fdtd_run_linked", "fdtd_half_step",
+    "fdtd_get_step", "fdtd_energy", "fdtd_p2p_export", "fdtd_p2p_attach", "fdtd_p2p_selftest", "fdtd_p2p_detach", "fdtd_comm_unique_id", "fdtd_comm_init", "fdtd_comm_nranks", "fdtd_link", "fdtd_run_linked", "fdtd_half_step",
     "fdtd_halo_get", "fdtd_halo_put", "fdtd_get_field", "fdtd_set_field", "fdtd_farfield",
 ]
 
@@ -86,6 +86,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
         "fdtd_p2p_detach": (C.c_int, [p]),
         "fdtd_comm_unique_id": (C.c_int, [p]),
         "fdtd_comm_init": (C.c_int, [p, p]),
+        "fdtd_comm_nranks": (C.c_int, [p, C.POINTER(C.c_int)]),
         "fdtd_link": (C.c_int, [p, p]),
         "fdtd_run_linked": (C.c_int, [C.POINTER(p), C.c_int, C.c_int]),
         "fdtd_half_step": (C.c_int, [p, C.c_int]),
@@ -393,6 +394,12 @@ class Engine:
 
     def p2p_detach(self):
         self._ck(self.lib.fdtd_p2p_detach(self._ctx), "p2p_detach")
+
+    def comm_nranks(self) -> int:
+        """Ranks of the RCCL communicator attached to this context (0: none)."""
+        n = C.c_int(0)
+        self._ck(self.lib.fdtd_comm_nranks(self._ctx, C.byref(n)), "comm_nranks")
+        return n.value
 
     def comm_init(self, uid: bytes):
         if len(uid) != 128:

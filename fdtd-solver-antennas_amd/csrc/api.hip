@@ -211,7 +211,7 @@ void fdtd_destroy(fdtd_ctx* c) {
   if (c->comm) ncclCommDestroy((ncclComm_t)c->comm);
   for (int n = 0; n < 6; ++n) hipFree(c->fieldbase[n]);
   hipFree(c->vv); hipFree(c->vi); hipFree(c->ii); hipFree(c->iv); hipFree(c->ecls); hipFree(c->lut); hipFree(c->met);
-  hipFree(c->cpcoef);
+  hipFree(c->cpcoef); hipFree(c->xc_tab);
   for (int n = 0; n < 12; ++n) hipFree(c->psi[n]);
   for (int f = 0; f < 6; ++f) { hipFree(c->mur[f].st[0]); hipFree(c->mur[f].st[1]); }
   hipFree(c->sig); hipFree(c->src_off); hipFree(c->src_comp); hipFree(c->src_amp); hipFree(c->src_delay);
@@ -369,6 +369,20 @@ int fdtd_set_cpml(fdtd_ctx* c, const int32_t* sx, const int32_t* sy, const int32
   for (int a = 0; a < 3; ++a)
     for (int eh = 0; eh < 2; ++eh)
       for (int w = 0; w < 3; ++w) c->p.cp[a][eh][w] = c->cpcoef + tab_off[a][eh][w];
+  // x-layer coefficients once more, compact and in psi-slot order, for the kernels' LDS table (kernel_common.hpp)
+  hipFree(c->xc_tab); c->xc_tab = nullptr; c->p.xc_tab = nullptr;
+  if (c->p.nslot[0] > 0 && c->p.nslot[0] <= 128) {
+    std::vector<float> xt((size_t)2 * 3 * 128);
+    for (int eh = 0; eh < 2; ++eh)
+      for (int w = 0; w < 3; ++w)
+        for (int sx = 0; sx < 128; ++sx) {
+          const int i = sx < c->p.pml_lo[0] ? sx : sx - c->p.pml_hi_slot[0] + c->p.pml_hi[0];
+          xt[((size_t)eh * 3 + w) * 128 + sx] = (sx < c->p.nslot[0] && i < len[0]) ? host[tab_off[0][eh][w] + i] : (w == 2 ? 1.f : 0.f);
+        }
+    HIPCK(c, hipMalloc(&c->xc_tab, xt.size() * sizeof(float)));
+    HIPCK(c, hipMemcpy(c->xc_tab, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->p.xc_tab = c->xc_tab;
+  }
   // psi: axis x -> [nk][ny][nsx]; y -> [nk][nsy][P]; z -> [nsz][ny][P]
   const size_t psz[3] = {(size_t)nk * ny * c->p.nslot[0], (size_t)nk * nsy * P, (size_t)nsz * ny * P};
   for (int n = 0; n < 12; ++n) { hipFree(c->psi[n]); c->psi[n] = nullptr; }
@@ -1464,6 +1478,13 @@ int fdtd_comm_init(fdtd_ctx* c, const void* uid128) {
     NCCLCK(c, ncclCommInitRank(&comm, c->d.world, id, c->d.rank));
   }
   c->comm = comm;
+  return FDTD_OK;
+}
+
+int fdtd_comm_nranks(fdtd_ctx* c, int* nranks) {
+  if (!c || !nranks) return fdtd_fail(c, FDTD_E_ARG, "null argument");
+  *nranks = 0;
+  if (c->comm) NCCLCK(c, ncclCommCount((ncclComm_t)c->comm, nranks));
   return FDTD_OK;
 }
 

@@ -59,6 +59,7 @@ struct DevParams {
   // (slot q - pml_hi[a] + pml_hi_slot[a]); pml_hi[a] >= n_a disables the upper layer.
   int pml_lo[3], pml_hi[3], pml_hi_slot[3], nslot[3];
   const float* cp[3][2][3];  // [axis][E-loc/H-loc][b, c, 1/kappa]
+  const float* xc_tab;       // [E-loc/H-loc][b, c, 1/kappa][XC_MAX]: the x-layer cells' coefficients in psi-slot order (null: more than XC_MAX)
   float* psiE[3][2];
   float* psiH[3][2];
   float* psiEn[3][2];        // fused kernel: next-step psi_E (ping-pong); psi_H is updated in place
@@ -130,6 +131,7 @@ struct fdtd_ctx {
   // cpml
   bool have_cpml = false;
   float* cpcoef = nullptr;
+  float* xc_tab = nullptr;       // compact x-layer coefficient table (DevParams::xc_tab)
   float* psi[12] = {};
   // mur
   MurFace mur[6] = {};

@@ -207,28 +207,144 @@ __device__ __forceinline__ void cpml_row4(float4& d, float* base, const unsigned
   d.w = __builtin_fmaf(ik, d.w, ps.w);
 }
 
-// x-directed layers: per-cell coefficients, psi stored [k][j][nslot_x]
+// ---- CPML psi through LDS-DMA ------------------------------------------------------------------------------------------
+// The psi loads of a layer cell depend on nothing but the cell's indices, yet they are only USED after the curl
+// differences exist.  Issued there (round 1) they are a second, exposed memory round trip for every wave that touches a
+// layer — measured on MI355X: the x layers (6 % of the cells, but some lanes of EVERY wave) cost 39 us of a 242 us step at
+// 400x400x80, the z layers 30 us.  Issued early into registers they cost 8 VGPRs per axis and a wave of occupancy.  So they
+// are issued early into LDS instead (global_load_lds_dwordx4: no register destination), right behind the field loads,
+// and read back from LDS when the differences are ready.  Each wave owns PSI_SLOTS KiB of staging, lane-linear per slot
+// (the LDS destination of an LDS-DMA load is wave-uniform base + lane * 16): slots 0,1 the x-directed pair, 2,3 the z pair.
+#ifndef FDTD_PSI_STAGE
+#define FDTD_PSI_STAGE 1
+#endif
+constexpr int PSI_SLOTS = 4;
+constexpr int XC_MAX = 128;   // x-layer cells (both sides, 4-aligned) whose (b, c, 1/kappa) fit the LDS coefficient table
+__device__ __forceinline__ unsigned lds_off(const void* q) { return (unsigned)(size_t)q; }   // LDS byte address of a __shared__ object
+// one 16-byte LDS-DMA load per active lane: global gsrc -> LDS lds_dst + lane*16 (lds_dst wave-uniform).  M0 is the
+// destination base and compiler-reserved: saved and restored inside the statement.  Not counted by the compiler's
+// s_waitcnt bookkeeping: loads issued BEFORE it only get waited for more conservatively (vmcnt retires in order);
+// the reader waits with an explicit vmcnt(0).
+__device__ __forceinline__ void glds16(const float* gsrc, const unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// the same with scalar base + 32-bit unsigned byte offset per lane (one address VGPR instead of a pair)
+__device__ __forceinline__ void glds16o(const float* base, const unsigned e, const unsigned lds_dst) {
+  unsigned keep;
+  const unsigned boff = e << 2;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(boff), "s"(lds_dst), "s"(base) : "memory");
+}
+__device__ __forceinline__ void sto4(float* base, const unsigned e, const float4& v) {
+  *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + (e << 2)) = v;
+}
+__device__ __forceinline__ void cpml_row4_reg(float4& d, float4& ps, float b, float c, float ik) {
+  ps.x = __builtin_fmaf(b, ps.x, c * d.x);
+  ps.y = __builtin_fmaf(b, ps.y, c * d.y);
+  ps.z = __builtin_fmaf(b, ps.z, c * d.z);
+  ps.w = __builtin_fmaf(b, ps.w, c * d.w);
+  d.x = __builtin_fmaf(ik, d.x, ps.x);
+  d.y = __builtin_fmaf(ik, d.y, ps.y);
+  d.z = __builtin_fmaf(ik, d.z, ps.z);
+  d.w = __builtin_fmaf(ik, d.w, ps.w);
+}
+
+// x-directed layers: per-cell coefficients, psi stored [k][j][nslot_x].  Both x ranges of the internal layout start on a
+// 4-cell boundary (fdtd_set_cpml), so a thread's four cells are ONE aligned float4 of psi and of each coefficient table
+// (cells drawn into the aligned range from outside the real layer, and pad cells, carry identity coefficients).
+__device__ __forceinline__ void cpml_x4_apply(float4& d, float4& ps, const float4& b, const float4& c, const float4& ik) {
+  ps.x = __builtin_fmaf(b.x, ps.x, c.x * d.x);
+  ps.y = __builtin_fmaf(b.y, ps.y, c.y * d.y);
+  ps.z = __builtin_fmaf(b.z, ps.z, c.z * d.z);
+  ps.w = __builtin_fmaf(b.w, ps.w, c.w * d.w);
+  d.x = __builtin_fmaf(ik.x, d.x, ps.x);
+  d.y = __builtin_fmaf(ik.y, d.y, ps.y);
+  d.z = __builtin_fmaf(ik.z, d.z, ps.z);
+  d.w = __builtin_fmaf(ik.w, d.w, ps.w);
+}
 __device__ __forceinline__ void cpml_x4(const DevParams& p, int eh, int i0, int rowslot, float4& da, float* psia,
                                         float4& db, float* psib) {
-  float a[4] = {da.x, da.y, da.z, da.w};
-  float bb[4] = {db.x, db.y, db.z, db.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int i = i0 + e;
-    const int sx = pml_slot(p, 0, i);
-    if (sx >= 0 && i < p.nx) {
-      const float b = p.cp[0][eh][0][i], c = p.cp[0][eh][1][i], ik = p.cp[0][eh][2][i];
-      const int o = rowslot + sx;
-      float ps = __builtin_fmaf(b, psia[o], c * a[e]);
-      psia[o] = ps;
-      a[e] = __builtin_fmaf(ik, a[e], ps);
-      ps = __builtin_fmaf(b, psib[o], c * bb[e]);
-      psib[o] = ps;
-      bb[e] = __builtin_fmaf(ik, bb[e], ps);
-    }
+  const int sx = i0 < p.pml_lo[0] ? i0 : i0 - p.pml_hi[0] + p.pml_hi_slot[0];
+  const float4 b = ld4(p.cp[0][eh][0] + i0), c = ld4(p.cp[0][eh][1] + i0), ik = ld4(p.cp[0][eh][2] + i0);
+  float* qa = psia + rowslot + sx;
+  float* qb = psib + rowslot + sx;
+  float4 pa = ld4(qa), pb = ld4(qb);
+  cpml_x4_apply(da, pa, b, c, ik);
+  cpml_x4_apply(db, pb, b, c, ik);
+  st4(qa, pa);
+  st4(qb, pb);
+}
+
+// Issue the LDS-DMA loads of the x- and z-directed psi pairs of this thread's cell group (E: eh = 0, H: eh = 1).
+// ox / oz: element offsets into the psi arrays, -1 when the group is outside that layer.
+__device__ __forceinline__ int psi_off_x(const DevParams& p, const int k, const int j, const int i0) {   // -1: outside the x layers
+  if (!(i0 < p.pml_lo[0] || i0 >= p.pml_hi[0])) return -1;   // both bounds are multiples of 4: all four cells or none
+  return (k * p.ny + j) * p.nslot[0] + (i0 < p.pml_lo[0] ? i0 : i0 - p.pml_hi[0] + p.pml_hi_slot[0]);
+}
+__device__ __forceinline__ int psi_off_z(const DevParams& p, const int k, const int j, const int i0) {
+  const int sz = pml_slot(p, 2, k);
+  return sz < 0 ? -1 : (sz * p.ny + j) * p.P + i0;
+}
+__device__ __forceinline__ int psi_off_y(const DevParams& p, const int k, const int j, const int i0) {
+  const int sy = pml_slot(p, 1, j);
+  return sy < 0 ? -1 : (k * p.nslot[1] + sy) * p.P + i0;
+}
+// (the y-directed pair stays a direct load in the kernels: staging it as well — tried, slots 2,3 where no z pair sits —
+// pushed both kernels over their register budget; the y layers are 5-7 % of the blocks)
+__device__ __forceinline__ void psi_stage_issue(const DevParams& p, float* const (&psi)[3][2], const unsigned stage, const bool valid,
+                                                const int k, const int j, const int i0) {
+  if (!valid) return;
+  const int ox = psi_off_x(p, k, j, i0);
+  if (ox >= 0) {
+    glds16o(psi[1][1], (unsigned)ox, stage);
+    glds16o(psi[2][0], (unsigned)ox, stage + 1024u);
   }
-  da = make_float4(a[0], a[1], a[2], a[3]);
-  db = make_float4(bb[0], bb[1], bb[2], bb[3]);
+  const int oz = psi_off_z(p, k, j, i0);
+  if (oz >= 0) {
+    glds16o(psi[0][1], (unsigned)oz, stage + 2048u);
+    glds16o(psi[1][0], (unsigned)oz, stage + 3072u);
+  }
+}
+// ... and use them: z pair on (dzA, dzB) = the two differences taken along z, x pair on (dxA, dxB) = along x.
+__device__ __forceinline__ void psi_stage_apply(const DevParams& p, float* const (&psi)[3][2], const int eh, const float4* s_psi, const float* s_xc,
+                                                const bool xc_lds, const int k, const int j, const int i0,
+                                                float4& dzA, float4& dzB, float4& dxA, float4& dxB) {
+  const int ox = psi_off_x(p, k, j, i0), oz = psi_off_z(p, k, j, i0);   // recomputed, not carried: registers
+  const float4* mine = s_psi + (threadIdx.x >> 6) * (PSI_SLOTS * 64) + (threadIdx.x & 63u);
+  // one psi array at a time, fenced: the scheduler would otherwise keep all four staged values and the coefficient vectors
+  // live at once, and this kernel has no registers to spare
+  if (oz >= 0) {
+    const float b = p.cp[2][eh][0][k], c = p.cp[2][eh][1][k], ik = p.cp[2][eh][2][k];
+    float4 ps = mine[2 * 64];
+    cpml_row4_reg(dzA, ps, b, c, ik);
+    sto4(psi[0][1], (unsigned)oz, ps);
+    __builtin_amdgcn_sched_barrier(0);
+    ps = mine[3 * 64];
+    cpml_row4_reg(dzB, ps, b, c, ik);
+    sto4(psi[1][0], (unsigned)oz, ps);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (ox >= 0) {
+    float4 b, c, ik;
+    if (xc_lds) {
+      const int sx = i0 < p.pml_lo[0] ? i0 : i0 - p.pml_hi[0] + p.pml_hi_slot[0];
+      b = *reinterpret_cast<const float4*>(s_xc + sx);
+      c = *reinterpret_cast<const float4*>(s_xc + XC_MAX + sx);
+      ik = *reinterpret_cast<const float4*>(s_xc + 2 * XC_MAX + sx);
+    } else {
+      b = ld4(p.cp[0][eh][0] + i0); c = ld4(p.cp[0][eh][1] + i0); ik = ld4(p.cp[0][eh][2] + i0);
+    }
+    float4 ps = mine[0];
+    cpml_x4_apply(dxA, ps, b, c, ik);
+    sto4(psi[1][1], (unsigned)ox, ps);
+    __builtin_amdgcn_sched_barrier(0);
+    ps = mine[64];
+    cpml_x4_apply(dxB, ps, b, c, ik);
+    sto4(psi[2][0], (unsigned)ox, ps);
+  }
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ float4 upd4(const float4& ca, const float4& f, const float4& cb, const float4& d1,

@@ -35,10 +35,13 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // COEF: 0 raw arrays, 1 class byte per edge, 2 one packed class byte per cell
 template <int COEF, bool PML, bool FUSE, bool P2P>
-__global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const FastDiv fd_ps,
+__global__ __launch_bounds__(FDTD_BLOCK, (COEF == 0 && P2P) ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const FastDiv fd_ps,
                                                                             const long long step, const int extra, const unsigned nb_main) {
-  __shared__ float2 s_lut[COEF == 2 ? 768 : (COEF == 1 ? 256 : 1)];
-  __shared__ double s_red[FUSE ? FDTD_BLOCK : 1];
+  extern __shared__ float2 s_lut[];   // coefficient table, lut_n entries (dynamic: scenes use a few dozen of the up to 768)
+  // CPML psi staging (LDS-DMA, 16 KiB); the probe block borrows it for its reduction
+  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : (FUSE ? FDTD_BLOCK / 2 : 1)];
+  __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];   // (b, c, 1/kappa) of the x-layer cells, by psi slot
+  double* const s_red = reinterpret_cast<double*>(s_psi);
   __shared__ SrcStage s_src;
   if (FUSE && extra && blockIdx.x == gridDim.x - 1) {   // probe block: H-probes of the step just finished
     probe_block(p, FDTD_KIND_I, step - 1, s_red);
@@ -51,46 +54,48 @@ __global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MIN
     decode_block_fd(fd_ps, p.fd_nbs, extra, 0, strip, kk, pb);
     k = k_begin + kk;
   }
-  // coefficient table -> registers now, -> LDS after the field loads have been issued (loads return in order, so
-  // waiting for these few entries leaves the field loads in flight)
-  constexpr int NLUT = COEF == 2 ? 768 : (COEF == 1 ? 256 : 0);
-  constexpr int NLR = (NLUT + FDTD_BLOCK - 1) / FDTD_BLOCK;
-  float2 lut_r[NLR > 0 ? NLR : 1];
-#pragma unroll
-  for (int q = 0; q < NLR; ++q) {
-    const int e = q * FDTD_BLOCK + (int)threadIdx.x;
-    lut_r[q] = e < p.lut_n ? p.lut[e] : make_float2(0.f, 0.f);
+  // coefficient table -> LDS by LDS-DMA, issued FIRST: no staging registers (the kernel has none to spare), and since
+  // vector-memory operations retire in order a counted wait below leaves the field loads behind it in flight.
+  // Thread t moves entries 2t, 2t+1 (16 bytes; the destination of an LDS-DMA load is lane-linear, so the table lands
+  // in order); 768 entries take a second round of the first 128 threads.  The buffer is allocated for the full table.
+  if (COEF != 0) {
+    const unsigned w_lds = __builtin_amdgcn_readfirstlane(lds_off(s_lut) + (threadIdx.x >> 6) * 1024u);
+    const float* lsrc = reinterpret_cast<const float*>(p.lut) + 4 * (int)threadIdx.x;
+    if (2 * (int)threadIdx.x < p.lut_n) glds16(lsrc, w_lds);
+    if (COEF == 2 && 2 * ((int)threadIdx.x + FDTD_BLOCK) < p.lut_n) glds16(lsrc + 4 * FDTD_BLOCK, w_lds + 4096u);
   }
+  // (b, c, 1/kappa) of the x-layer cells in psi-slot order: a compact table the host laid out (fdtd_set_cpml), 3 x XC_MAX
+  // floats, to LDS by LDS-DMA as well (96 threads x 16 bytes)
+  const bool xc_lds = PML && FDTD_PSI_STAGE && p.xc_tab != nullptr;
+  if (xc_lds && (int)threadIdx.x < 3 * XC_MAX / 4)
+    glds16(p.xc_tab + 4 * (int)threadIdx.x, __builtin_amdgcn_readfirstlane(lds_off(s_xc) + (threadIdx.x >> 6) * 1024u));
   // the field loads are issued BEFORE the barrier that publishes the LDS tables, so that their latency overlaps
   // the table staging instead of following it (out-of-range threads of the last block read their block's first
   // group, in range by construction, and leave after the barrier)
   int j = 0, i0 = 0;
   const bool valid = decode_thread(p, strip, pb, j, i0);
   const int off = k * p.plane + (valid ? j * p.P + i0 : 0);
-  // scalar bases one plane below plane 0 (the ghost plane), so that every offset — also k-1, j-1, i-1 — is unsigned
+  // ONE per-lane offset for all thirteen loads: the neighbour displacements (k-1, j-1, i-1) go into the SCALAR base
+  // pointers (SGPRs are plentiful, VGPRs decide the occupancy); bases start one plane below plane 0 (the ghost plane), so
+  // that the offset stays unsigned whatever the displacement
   const unsigned uo = (unsigned)(off + p.plane);
   const float *I0 = p.I[0] - p.plane, *I1 = p.I[1] - p.plane, *I2 = p.I[2] - p.plane;
   const float4 ix = ldo4(I0, uo), iy = ldo4(I1, uo), iz = ldo4(I2, uo);
-  const float4 iz_jm = ldo4(I2, uo - p.P), ix_jm = ldo4(I0, uo - p.P);
+  const float4 iz_jm = ldo4(I2 - p.P, uo), ix_jm = ldo4(I0 - p.P, uo);
   // P2P: the k-1 neighbours of the bottom plane are the lower rank's top plane and come from the mailbox (below)
   const bool dep_in = P2P && k == 0 && p.mb_in_H != nullptr;
   float4 iy_km = make_float4(0.f, 0.f, 0.f, 0.f), ix_km = iy_km;
-  if (!dep_in) { iy_km = ldo4(I1, uo - p.plane); ix_km = ldo4(I0, uo - p.plane); }
-  const float iz_im = ldo1(I2, uo - 1), iy_im = ldo1(I1, uo - 1);
-  float4 vx = ldo4(p.V[0], (unsigned)off), vy = ldo4(p.V[1], (unsigned)off), vz = ldo4(p.V[2], (unsigned)off);
+  if (!dep_in) { iy_km = ldo4(I1 - p.plane, uo); ix_km = ldo4(I0 - p.plane, uo); }
+  const float iz_im = ldo1(I2 - 1, uo), iy_im = ldo1(I1 - 1, uo);
+  float4 vx = ldo4(p.V[0] - p.plane, uo), vy = ldo4(p.V[1] - p.plane, uo), vz = ldo4(p.V[2] - p.plane, uo);
   // soft sources inside this strip-plane (block-uniform range; almost always empty)
   int2 srng = make_int2(0, 0);
   if (FUSE && p.nsrc > 0) {
     srng = p.src_rng[k * p.nstrips + strip];
     stage_sources(p, p.src_ids, srng.x, min(srng.y - srng.x, FDTD_BLOCK), step, s_src);
   }
-#pragma unroll
-  for (int q = 0; q < NLR; ++q) {
-    const int e = q * FDTD_BLOCK + (int)threadIdx.x;
-    if (e < p.lut_n) s_lut[e] = lut_r[q];
-  }
-  if (COEF != 0 || (FUSE && p.nsrc > 0)) __syncthreads();
-  if (!valid) return;
+  if (PML && FDTD_PSI_STAGE)   // psi of the x / z layers: LDS-DMA right behind the field loads (kernel_common.hpp)
+    psi_stage_issue(p, p.psiE, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
   if (dep_in) {   // H halo of step-1 (flag value = steps delivered); parity of the step that produced it
     p2p_wait(p.fl_in + 1, (unsigned)step, p.p2p_err, p.p2p_limit);
     const float* mb = p.mb_in_H + (size_t)((step + 1) & 1) * 2 * p.plane + (j * p.P + i0);
@@ -106,6 +111,16 @@ __global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MIN
   float4 dz1 = make_float4(iy.x - iy_im, iy.y - iy.x, iy.z - iy.y, iy.w - iy.z);
   float4 dz2 = sub4(ix, ix_jm);
 
+  // ONE barrier, here: the differences above consumed every field load, so all older vector-memory operations — the
+  // LDS-DMA loads of the coefficient tables and of the staged psi — have landed as well (in-order retirement; the explicit
+  // wait is for the ones the compiler does not count), and no wave waits at the barrier for data it would not have
+  // waited for anyway.  Out-of-range threads computed on their block's first group and leave now.
+  if (COEF != 0 || (FUSE && p.nsrc > 0) || (PML && FDTD_PSI_STAGE)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (!valid) return;
+
   if (PML) {
     const int sy = pml_slot(p, 1, j);
     if (sy >= 0) {
@@ -114,15 +129,20 @@ __global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MIN
       cpml_row4(dx1, p.psiE[0][0], (unsigned)o, b, c, ik);
       cpml_row4(dz2, p.psiE[2][1], (unsigned)o, b, c, ik);
     }
-    const int sz = pml_slot(p, 2, k);
-    if (sz >= 0) {
-      const float b = p.cp[2][0][0][k], c = p.cp[2][0][1][k], ik = p.cp[2][0][2][k];
-      const int o = (sz * p.ny + j) * p.P + i0;
-      cpml_row4(dx2, p.psiE[0][1], (unsigned)o, b, c, ik);
-      cpml_row4(dy1, p.psiE[1][0], (unsigned)o, b, c, ik);
+    if (FDTD_PSI_STAGE) {
+      psi_stage_apply(p, p.psiE, 0, s_psi, s_xc, xc_lds, k, j, i0, dx2, dy1, dy2, dz1);
+    } else {
+      const int sz = pml_slot(p, 2, k);
+      if (sz >= 0) {
+        const float b = p.cp[2][0][0][k], c = p.cp[2][0][1][k], ik = p.cp[2][0][2][k];
+        const int o = (sz * p.ny + j) * p.P + i0;
+        cpml_row4(dx2, p.psiE[0][1], (unsigned)o, b, c, ik);
+        cpml_row4(dy1, p.psiE[1][0], (unsigned)o, b, c, ik);
+      }
+      if (i0 < p.pml_lo[0] || i0 >= p.pml_hi[0])   // both bounds are multiples of 4: all four cells or none
+        cpml_x4(p, 0, i0, (k * p.ny + j) * p.nslot[0], dy2, p.psiE[1][1], dz1, p.psiE[2][0]);
     }
-    if (i0 < p.pml_lo[0] || i0 + 3 >= p.pml_hi[0])
-      cpml_x4(p, 0, i0, (k * p.ny + j) * p.nslot[0], dy2, p.psiE[1][1], dz1, p.psiE[2][0]);
+    __builtin_amdgcn_sched_barrier(0);   // keep the coefficient loads of the update below out of the CPML section (registers)
   }
 
   // One component at a time — coefficients, update, sources, store — with a scheduling fence between the components:
@@ -181,31 +201,43 @@ __global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MIN
 // K2: H half-step
 // ------------------------------------------------------------------------------------------------
 template <bool RAW, bool PML, bool P2P>
-__global__ __launch_bounds__(FDTD_BLOCK, (P2P && RAW) ? FDTD_H_MINBLOCKS - 1 : FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const FastDiv fd_ps,
+__global__ __launch_bounds__(FDTD_BLOCK, RAW ? FDTD_H_MINBLOCKS - 1 : FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const FastDiv fd_ps,
                                                                             const long long step, const int extra, const unsigned nb_main) {
-  __shared__ double s_red[FDTD_BLOCK];
+  // CPML psi staging (LDS-DMA, 16 KiB); the probe block borrows it for its reduction
+  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : FDTD_BLOCK / 2];
+  __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
+  double* const s_red = reinterpret_cast<double*>(s_psi);
   if (extra && blockIdx.x == gridDim.x - 1) {   // probe block: V-probes of this step (V is final, H not read)
     probe_block(p, FDTD_KIND_V, step, s_red);
     return;
   }
-  int strip, kk, pb, j, i0, k;
+  int strip, kk, pb, j = 0, i0 = 0, k;
   if (P2P) {   // all planes in one launch, the halo-dependent top plane last
     decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, p.nk - 1, 0, strip, k, pb);
   } else {
     decode_block_fd(fd_ps, p.fd_nbs, extra, p.sweep_rev, strip, kk, pb);
     k = k_begin + kk;
   }
-  if (!decode_thread(p, strip, pb, j, i0)) return;
-  const int off = k * p.plane + j * p.P + i0;
+  const bool staged = PML && FDTD_PSI_STAGE;
+  const bool xc_lds = staged && p.xc_tab != nullptr;
+  if (xc_lds && (int)threadIdx.x < 3 * XC_MAX / 4)   // H-located (b, c, 1/kappa) of the x-layer cells: second half of the table
+    glds16(p.xc_tab + 3 * XC_MAX + 4 * (int)threadIdx.x, __builtin_amdgcn_readfirstlane(lds_off(s_xc) + (threadIdx.x >> 6) * 1024u));
+  // with psi staging the block meets at one barrier (x-layer coefficient table): out-of-range threads of a strip's last
+  // block read their block's first group (in range by construction) and leave after it
+  const bool valid = decode_thread(p, strip, pb, j, i0);
+  if (!staged && !valid) return;
+  const int off = k * p.plane + (valid ? j * p.P + i0 : 0);
 
   const unsigned uo = (unsigned)off;     // H reads planes k, k+1 only: offsets from plane 0 are never negative
   const float4 vx = ldo4(p.V[0], uo), vy = ldo4(p.V[1], uo), vz = ldo4(p.V[2], uo);
-  const float4 vz_jp = ldo4(p.V[2], uo + p.P), vx_jp = ldo4(p.V[0], uo + p.P);
+  const float4 vz_jp = ldo4(p.V[2] + p.P, uo), vx_jp = ldo4(p.V[0] + p.P, uo);   // neighbour displacements in the scalar bases: one offset VGPR
   const bool dep_in = P2P && k == p.nk - 1 && p.mb_in_E != nullptr;   // k+1 is the upper rank's bottom plane: mailbox
   float4 vy_kp = make_float4(0.f, 0.f, 0.f, 0.f), vx_kp = vy_kp;
-  if (!dep_in) { vy_kp = ldo4(p.V[1], uo + p.plane); vx_kp = ldo4(p.V[0], uo + p.plane); }
-  const float vz_ip = ldo1(p.V[2], uo + 4), vy_ip = ldo1(p.V[1], uo + 4);
+  if (!dep_in) { vy_kp = ldo4(p.V[1] + p.plane, uo); vx_kp = ldo4(p.V[0] + p.plane, uo); }
+  const float vz_ip = ldo1(p.V[2] + 4, uo), vy_ip = ldo1(p.V[1] + 4, uo);
   float4 ix = ldo4(p.I[0], uo), iy = ldo4(p.I[1], uo), iz = ldo4(p.I[2], uo);
+  if (staged)
+    psi_stage_issue(p, p.psiH, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
   if (dep_in) {   // E halo of this step
     p2p_wait(p.fl_in + 0, (unsigned)step + 1u, p.p2p_err, p.p2p_limit);
     const float* mb = p.mb_in_E + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
@@ -219,6 +251,12 @@ __global__ __launch_bounds__(FDTD_BLOCK, (P2P && RAW) ? FDTD_H_MINBLOCKS - 1 : F
   float4 dz1 = make_float4(vy.x - vy.y, vy.y - vy.z, vy.z - vy.w, vy.w - vy_ip);
   float4 dz2 = sub4(vx, vx_jp);
 
+  if (staged) {   // one barrier, where every wave has its loads anyway (see update_E): x-layer coefficient table + staged psi are in LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!valid) return;
+  }
+
   if (PML) {
     const int sy = pml_slot(p, 1, j);
     if (sy >= 0) {
@@ -227,15 +265,20 @@ __global__ __launch_bounds__(FDTD_BLOCK, (P2P && RAW) ? FDTD_H_MINBLOCKS - 1 : F
       cpml_row4(dx1, p.psiH[0][0], (unsigned)o, b, c, ik);
       cpml_row4(dz2, p.psiH[2][1], (unsigned)o, b, c, ik);
     }
-    const int sz = pml_slot(p, 2, k);
-    if (sz >= 0) {
-      const float b = p.cp[2][1][0][k], c = p.cp[2][1][1][k], ik = p.cp[2][1][2][k];
-      const int o = (sz * p.ny + j) * p.P + i0;
-      cpml_row4(dx2, p.psiH[0][1], (unsigned)o, b, c, ik);
-      cpml_row4(dy1, p.psiH[1][0], (unsigned)o, b, c, ik);
+    if (FDTD_PSI_STAGE) {
+      psi_stage_apply(p, p.psiH, 1, s_psi, s_xc, xc_lds, k, j, i0, dx2, dy1, dy2, dz1);
+    } else {
+      const int sz = pml_slot(p, 2, k);
+      if (sz >= 0) {
+        const float b = p.cp[2][1][0][k], c = p.cp[2][1][1][k], ik = p.cp[2][1][2][k];
+        const int o = (sz * p.ny + j) * p.P + i0;
+        cpml_row4(dx2, p.psiH[0][1], (unsigned)o, b, c, ik);
+        cpml_row4(dy1, p.psiH[1][0], (unsigned)o, b, c, ik);
+      }
+      if (i0 < p.pml_lo[0] || i0 >= p.pml_hi[0])
+        cpml_x4(p, 1, i0, (k * p.ny + j) * p.nslot[0], dy2, p.psiH[1][1], dz1, p.psiH[2][0]);
     }
-    if (i0 < p.pml_lo[0] || i0 + 3 >= p.pml_hi[0])
-      cpml_x4(p, 1, i0, (k * p.ny + j) * p.nslot[0], dy2, p.psiH[1][1], dz1, p.psiH[2][0]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   if (RAW) {
@@ -466,7 +509,8 @@ static void launch_main(fdtd_ctx* c, K kern, dim3 grid, unsigned lds, hipStream_
 
 template <int COEF, bool PML>
 static void launch_E2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long step, bool fused, int extra, hipStream_t s) {
-  const unsigned pad = lds_pad(c->occ_e, 11264u);
+  const unsigned lut_bytes = (unsigned)(c->raw_op ? 0 : (c->p.lut_n + 1) / 2) * 16u;   // dynamic LDS: the coefficient table, whole 16-byte LDS-DMA pieces
+  const unsigned pad = lut_bytes + lds_pad(c->occ_e, (PML && FDTD_PSI_STAGE ? 20480u : 4608u) + lut_bytes);
   if (c->p.p2p) {   // whole slab in one launch, bottom plane last (decode_block_p2p)
     const FastDiv fd_ps = make_fastdiv((unsigned)(nkr - 1) * (unsigned)c->p.nbs);
     const unsigned nb_main = (unsigned)c->p.nstrips * (unsigned)(nkr - 1) * (unsigned)c->p.nbs;
@@ -497,7 +541,7 @@ void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool f
 
 template <bool RAW, bool PML>
 static void launch_H2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long step, int extra, hipStream_t s) {
-  const unsigned pad = lds_pad(c->occ_h, 2560u);
+  const unsigned pad = lds_pad(c->occ_h, PML && FDTD_PSI_STAGE ? 18432u : 2560u);
   if (c->p.p2p) {
     const FastDiv fd_ps = make_fastdiv((unsigned)(nkr - 1) * (unsigned)c->p.nbs);
     const unsigned nb_main = (unsigned)c->p.nstrips * (unsigned)(nkr - 1) * (unsigned)c->p.nbs;

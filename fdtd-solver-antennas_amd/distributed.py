@@ -38,6 +38,7 @@ class SlabComm:
         self.transport_used = None
         self.rccl_error = None
         self.p2p_error = None
+        self.ms_exchange = 0.0       # host transport: wall time spent in halo exchanges
 
     # -- tensors on the right device for the process group ------------------------------------------
     def _to_t(self, a: np.ndarray):
@@ -125,6 +126,8 @@ class SlabComm:
     # -- host transport: one exchange after each half-step ------------------------------------------
     def exchange(self, eng, which: int):
         """HALO_E_DOWN: bottom Vx,Vy plane -> rank-1 (ghost above there); HALO_H_UP: top Ix,Iy -> rank+1."""
+        import time
+        t0 = time.perf_counter()
         r, w = self.rank, self.world
         dst, src = (r - 1, r + 1) if which == _capi.HALO_E_DOWN else (r + 1, r - 1)
         ops, recv = [], None
@@ -138,6 +141,7 @@ class SlabComm:
                 req.wait()
         if recv is not None:
             eng.halo_put(which, recv.cpu().numpy())
+        self.ms_exchange += (time.perf_counter() - t0) * 1e3
 
     def run_steps(self, eng, nsteps: int):
         for _ in range(nsteps):

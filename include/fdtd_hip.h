@@ -211,6 +211,8 @@ int fdtd_energy(fdtd_ctx* ctx, double sums[2]);
  *     128 bytes to every rank (e.g. torch.distributed broadcast), every rank calls comm_init. */
 int fdtd_comm_unique_id(void* out128);
 int fdtd_comm_init(fdtd_ctx* ctx, const void* uid128);
+/* Ranks of the RCCL communicator this context steps through (ncclCommCount); 0 when none is attached. */
+int fdtd_comm_nranks(fdtd_ctx* ctx, int* nranks);
 /* (a0) P2P mailbox transport — the default for one process per GPU: the update kernels push the outgoing halo plane
  *      straight into the neighbour's mailbox (peer / IPC mapping, xGMI stores) and publish a step counter there; the
  *      neighbour's kernel waits for the counter before it touches the halo-dependent plane, which it schedules last.

@@ -797,6 +797,7 @@ int fdtd_p2p_selftest(fdtd_ctx* c, unsigned token) { (void)token; return fail(c,
 int fdtd_p2p_detach(fdtd_ctx* c) { return c ? FDTD_OK : FDTD_E_ARG; }
 int fdtd_comm_unique_id(void* out128) { (void)out128; return fail(NULL, FDTD_E_UNSUPPORTED, "oracle has no RCCL transport"); }
 int fdtd_comm_init(fdtd_ctx* c, const void* uid) { (void)uid; return fail(c, FDTD_E_UNSUPPORTED, "oracle has no RCCL transport"); }
+int fdtd_comm_nranks(fdtd_ctx* c, int* nranks) { if (!c || !nranks) return FDTD_E_ARG; *nranks = 0; return FDTD_OK; }
 
 int fdtd_halo_get(fdtd_ctx* c, int which, float* buf) {
   if (!c || !buf) return FDTD_E_ARG;

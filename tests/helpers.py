@@ -5,12 +5,13 @@ from conftest import pkg
 
 
 def patch_sim(nx, ny, nz, *, boundary="CPML", cpml_cells=8, nr_ts=400, use_classes=True, nf2ff=True,
-              f0=2.45e9):
+              f0=2.45e9, nf2ff_freqs=None, nf2ff_mode="dft"):
     wl, sc, sim = pkg("workloads"), pkg("scene"), pkg("simulation")
     w = wl.patch_workload("test", nx=nx, ny=ny, nz=nz, f0=f0)
     vox = sc.voxelize(w.scene, w.grid)
     return sim.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary=boundary, cpml_cells=cpml_cells,
-                          nr_ts=nr_ts, nf2ff_freqs=[w.f0] if nf2ff else None, use_classes=use_classes)
+                          nr_ts=nr_ts, nf2ff_freqs=(nf2ff_freqs if nf2ff_freqs is not None else [w.f0]) if nf2ff else None,
+                          use_classes=use_classes, nf2ff_mode=nf2ff_mode)
 
 
 def seeded_fields(engine, seed=0, scale=1e-3):

@@ -251,23 +251,64 @@ def test_plugin_path_s11_and_patterns_gpu_vs_oracle(hip_lib, oracle_lib, tmp_pat
     assert data["ok"] and len(data["e_plane_dBi"]) == 46
 
 
-def test_multi_patch_rotated_runs_on_gpu(hip_lib, tmp_path):
+def test_multi_patch_rotated_two_ports_gpu_vs_oracle(hip_lib, oracle_lib, tmp_path):
     """Two elements, one rotated 90 deg about z and lifted, finite-thickness copper, volumetric lumped ports
-    (multi_3d variant): runs on the GPU, both ports deliver series, pattern is finite."""
+    (multi_3d variant = BASELINE config 5's geometry class) through the plugin surface on the HIP library and on
+    the oracle: S11 of BOTH ports, both port series and the E/H-plane cuts within 1e-3 relative L2."""
     s = pkg("solver_fdtd_hip")
+    sink = pkg("result_sink")
     P = pkg("params").PatchAntennaParams
     p = P.from_user_units(frequency_ghz=5.8, er=4.3, h_mm=1.6, loss_tangent=0.02, metal_thickness_um=200.0)
     arr = [s.PatchInstance("A", p, -0.02, 0.0, 0.0, s.FeedDirection.NEG_X),
            s.PatchInstance("B", p, 0.02, 0.0, 0.002, s.FeedDirection.NEG_Y, rot_z_deg=90.0)]
-    prep = s.prepare_hip_microstrip_multi_3d(arr, boundary="PML_8", theta_step_deg=6.0, phi_step_deg=30.0, mesh_quality=1,
-                                             auto_margin_mm=(25.0, 25.0, 30.0), work_dir=str(tmp_path / "m"))
-    assert prep.ok, prep.message
-    prep.FDTD.NrTS = 1500
-    r = s.run_prepared_hip(prep, frequency_hz=5.8e9, verbose=0)
-    assert r.ok, r.message
-    assert np.isfinite(r.intensity).all() and r.intensity.shape == (31, 13)
-    series = prep.FDTD.sim.port_series()
-    assert len(series) == 2 and all(np.abs(u).max() > 0 and np.abs(i).max() > 0 for u, i in series)
+    out = []
+    for lib, tag in ((hip_lib, "gpu"), (oracle_lib, "cpu")):
+        prep = s.prepare_hip_microstrip_multi_3d(arr, boundary="PML_8", theta_step_deg=6.0, phi_step_deg=30.0, mesh_quality=1,
+                                                 auto_margin_mm=(25.0, 25.0, 30.0), work_dir=str(tmp_path / tag), lib=lib)
+        assert prep.ok, prep.message
+        prep.FDTD.NrTS = 1500
+        r = s.run_prepared_hip(prep, frequency_hz=5.8e9, verbose=0)
+        assert r.ok, r.message
+        assert np.isfinite(r.intensity).all() and r.intensity.shape == (31, 13)
+        series = prep.FDTD.sim.port_series()
+        assert len(series) == 2 and all(np.abs(u).max() > 0 and np.abs(i).max() > 0 for u, i in series)
+        s11 = [s.s11_from_port(port, prep.sim_path, 5.8e9)[1] for port in prep.ports]
+        out.append((r, series, s11))
+    (g, sg, s11g), (c, sc_, s11c) = out
+    assert g.stats["grid"] == c.stats["grid"] and g.stats["steps"] == c.stats["steps"]
+    for q in range(2):
+        assert rel_l2(sg[q][0], sc_[q][0]) < 1e-4 and rel_l2(sg[q][1], sc_[q][1]) < 1e-4
+        assert rel_l2(s11g[q], s11c[q]) < 1e-3
+    _, ge, gh = sink.principal_cuts(g.theta, g.phi, g.intensity)
+    _, ce, ch = sink.principal_cuts(c.theta, c.phi, c.intensity)
+    lin = lambda d: 10.0 ** (np.asarray(d) / 20.0)
+    assert rel_l2(lin(ge), lin(ce)) < 1e-3 and rel_l2(lin(gh), lin(ch)) < 1e-3
+    assert abs(g.Dmax - c.Dmax) < 1e-6 * c.Dmax
+
+
+def test_fixed_scene_mur_end_criterion_gpu_vs_oracle(hip_lib, oracle_lib, tmp_path):
+    """The scene the reference's GUI runs by default (prepare_*_patch_fixed: graded mesh, MUR on all faces, lumped port,
+    end criterion -40 dB: solver_fdtd_openems_fixed.py:113-342) through the plugin surface on the HIP library and on
+    the oracle: both stop at the same step, S11(f), the port series and the two pattern cuts within 1e-3."""
+    s = pkg("solver_fdtd_hip")
+    P = pkg("params").PatchAntennaParams
+    p = P.from_user_units(frequency_ghz=2.45, er=4.3, h_mm=1.6, loss_tangent=0.02)
+    res = []
+    for lib, tag in ((hip_lib, "gpu"), (oracle_lib, "cpu")):
+        prep = s.prepare_hip_patch_fixed(p, work_dir=str(tmp_path / tag), lib=lib)
+        assert prep.ok, prep.message
+        r = s.run_prepared_hip(prep, frequency_hz=p.frequency_hz, verbose=0)
+        assert r.ok, r.message
+        res.append(r)
+    g, c = res
+    assert g.intensity.shape == c.intensity.shape == (90, 2)
+    assert g.stats["grid"] == c.stats["grid"] and g.stats["steps"] == c.stats["steps"] < 30000   # stopped by the energy criterion
+    assert g.stats["energy_db"] < -40.0
+    assert rel_l2(g.port_u, c.port_u) < 1e-4 and rel_l2(g.port_i, c.port_i) < 1e-4
+    assert rel_l2(g.s11, c.s11) < 1e-3
+    lin = lambda d: 10.0 ** (np.asarray(d) / 20.0)
+    assert rel_l2(lin(g.intensity), lin(c.intensity)) < 1e-3
+    assert abs(g.Dmax - c.Dmax) < 1e-6 * c.Dmax
 
 
 def test_northstar_acceptance(hip_lib, oracle_lib):
@@ -323,10 +364,27 @@ def test_rccl_self_loopback_transport(hip_lib, oracle_lib, overlap):
     assert not same_values(e0.fields(), outs[0])
 
 
-def _attach_p2p(engs):
+def _attach_p2p(engs, selftest=False):
     blobs = [e.p2p_export() for e in engs]
     for r, e in enumerate(engs):
         e.p2p_attach(blobs[r - 1] if r > 0 else None, blobs[r + 1] if r + 1 < len(engs) else None)
+    if selftest:
+        # the self-test waits for the neighbours' tokens: all ranks must be in it at the same time (one host thread each;
+        # ctypes releases the GIL).  It pushes pattern planes through the real data path and restores the zeros after.
+        import threading
+        errs = []
+
+        def one(e):
+            try:
+                e.p2p_selftest(0x5E1F0003)
+            except Exception as exc:      # noqa: BLE001
+                errs.append(exc)
+        th = [threading.Thread(target=one, args=(e,)) for e in engs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
 
 
 @pytest.mark.parametrize("world", [2, 3, 5])
@@ -340,7 +398,7 @@ def test_p2p_mailbox_transport_slabs_equal_one_slab(hip_lib, world):
     e1.run(260)
     sims = [patch_sim(56, 52, 34, nr_ts=260) for _ in range(world)]
     engs = [s.build(hip_lib, rank=r, world=world) for r, s in enumerate(sims)]
-    _attach_p2p(engs)
+    _attach_p2p(engs, selftest=(world == 3))
     for n in (1, 100, 159):
         capi.run_linked(engs, n)
     f2 = np.concatenate([e.fields() for e in engs], axis=2)
@@ -402,10 +460,11 @@ def test_mur_with_sources_next_to_and_away_from_a_face(hip_lib, oracle_lib, src_
     assert rel_l2(uh, uo) < 1e-12 and rel_l2(ih, io) < 1e-12
 
 
-def test_largest_baseline_grid_two_p2p_slabs_equal_one(hip_lib):
+def test_largest_baseline_grid_two_p2p_slabs_equal_one(hip_lib, oracle_lib):
     """BASELINE's largest configuration (C5: 800x800x120, 2x2 array, four lumped ports, 76.8 Mcells) at full size:
-    two z-slabs coupled by the P2P mailbox transport reproduce the single-slab run bit for bit — exercises the index
-    arithmetic, the source lists and the mailboxes at the sizes the 8-GPU configuration is quoted on."""
+    the single-slab HIP run equals the ORACLE on every field value and port series, and two z-slabs coupled by the P2P
+    mailbox transport reproduce the single-slab run bit for bit — exercises the index arithmetic, the source lists and
+    the mailboxes at the sizes the 8-GPU configuration is quoted on."""
     capi, sim_m, wl, sc = pkg("_capi"), pkg("simulation"), pkg("workloads"), pkg("scene")
     w = wl.baseline_workload("C5")
     vox = sc.voxelize(w.scene, w.grid)
@@ -420,6 +479,17 @@ def test_largest_baseline_grid_two_p2p_slabs_equal_one(hip_lib):
     ref = [e1.get_field(kind, comp) for kind in (0, 1) for comp in range(3)]
     u1 = [np.asarray(s1.port_series()[q][0]) for q in range(len(vox.ports))]
     del e1, s1
+    so = make()
+    eo = so.build(oracle_lib)
+    eo.run(steps)
+    n = 0
+    for kind in (0, 1):
+        for comp in range(3):
+            assert same_values(ref[n], eo.get_field(kind, comp)), ("HIP vs oracle", kind, comp)
+            n += 1
+    for q in range(len(vox.ports)):
+        assert rel_l2(u1[q], np.asarray(so.port_series()[q][0])) < 1e-12
+    del eo, so
     sims = [make(), make()]
     engs = [s.build(hip_lib, rank=r, world=2) for r, s in enumerate(sims)]
     _attach_p2p(engs)
@@ -455,3 +525,150 @@ def test_c4_full_size_gpu_equals_oracle(hip_lib, oracle_lib):
     for a, b in zip(fh, fo):
         assert same_values(a, b)
     assert rel_l2(uh, uo) < 1e-12
+
+
+@pytest.mark.parametrize("name,steps", [("C2", 300), ("C3", 90)])
+def test_c2_c3_full_size_gpu_equals_oracle(hip_lib, oracle_lib, name, steps):
+    """BASELINE configs 2 and 3 at full size (200x200x40 and 400x400x80, fixed scene, CPML-10) WITH the NF2FF surfaces
+    recording: every field value identical to the oracle, port series and all 24 DFT boxes to 1e-12."""
+    sim_m, wl, sc = pkg("simulation"), pkg("workloads"), pkg("scene")
+    w = wl.baseline_workload(name)
+    vox = sc.voxelize(w.scene, w.grid)
+    out = []
+    for lib in (hip_lib, oracle_lib):
+        s = sim_m.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=10, nr_ts=steps + 8, nf2ff_freqs=[w.f0])
+        e = s.build(lib)
+        e.run(steps)
+        out.append(([e.get_field(kind, comp) for kind in (0, 1) for comp in range(3)], np.asarray(s.port_series()[0][0]),
+                    np.asarray(s.port_series()[0][1]), s.nf2ff_boxes(), s.dft_every))
+        del e, s
+    (fh, uh, ih, bh, every), (fo, uo, io, bo, _) = out
+    assert steps > 2 * every                       # the surfaces took several samples
+    assert max(np.abs(a).max() for a in fo) > 0 and np.abs(uo).max() > 0
+    for a, b in zip(fh, fo):
+        assert same_values(a, b)
+    assert rel_l2(uh, uo) < 1e-12 and rel_l2(ih, io) < 1e-12
+    assert len(bh) == len(bo) == 24
+    for a, b in zip(bh, bo):
+        assert a.shape == b.shape and rel_l2(a, b) < 1e-12
+    assert max(np.abs(b).max() for b in bo) > 0
+
+
+@pytest.mark.parametrize("nfreq", [3, 16])
+def test_multi_frequency_dft_boxes(hip_lib, oracle_lib, nfreq):
+    """Running DFT with nfreq > 1 (the k_dft frequency loop): 3 and 16 frequencies over the reference's S11 band,
+    HIP vs oracle 1e-12 on all 24 boxes, and the f0 column equals a single-frequency run bit for bit."""
+    f0 = 2.45e9
+    freqs = np.linspace(0.7 * f0, 1.3 * f0, nfreq)
+    freqs[nfreq // 2] = f0
+    (sh, eh), (so, eo) = _run_both(lambda: patch_sim(64, 60, 36, nr_ts=900, nf2ff_freqs=freqs), hip_lib, oracle_lib, 900)
+    bh, bo = sh.nf2ff_boxes(), so.nf2ff_boxes()
+    assert len(bh) == 24 and bh[0].shape[0] == nfreq
+    for a, b in zip(bh, bo):
+        assert rel_l2(a, b) < 1e-12
+    s1 = patch_sim(64, 60, 36, nr_ts=900)
+    s1.dft_every, s1.dft_nsamples = sh.dft_every, sh.dft_nsamples      # same sampling as the multi-frequency run
+    e1 = s1.build(hip_lib)
+    e1.run(900)
+    for a, b in zip(bh, s1.nf2ff_boxes()):
+        assert np.array_equal(a[nfreq // 2], b[0])
+
+
+def test_recorder_equals_running_dft_and_oracle(hip_lib, oracle_lib):
+    """Time-domain recording of the NF2FF faces (fdtd_set_recorder / fdtd_rec_transform): transformed afterwards at
+    the frequencies a running-DFT run had fixed beforehand it gives the same bits (same float64 fma chain); any other
+    frequency afterwards agrees with the oracle's recorder to 1e-12; chunked runs record the same samples."""
+    f0 = 2.45e9
+    freqs = np.array([0.8 * f0, f0, 1.17 * f0])
+    sd = patch_sim(64, 60, 36, nr_ts=900, nf2ff_freqs=freqs)
+    ed = sd.build(hip_lib)
+    ed.run(900)
+    sr = patch_sim(64, 60, 36, nr_ts=900, nf2ff_freqs=freqs, nf2ff_mode="record")
+    assert sr.nf2ff_mode == "record" and sr.dft_every == sd.dft_every
+    er = sr.build(hip_lib)
+    for n in (1, 299, 600):
+        er.run(n)
+    for a, b in zip(sd.nf2ff_boxes(), sr.nf2ff_boxes()):
+        assert np.array_equal(a, b)
+    so = patch_sim(64, 60, 36, nr_ts=900, nf2ff_freqs=freqs, nf2ff_mode="record")
+    eo = so.build(oracle_lib)
+    eo.run(900)
+    other = np.array([1.9135e9, 2.2e9])
+    bh, bo = sr.nf2ff_boxes(freqs=other), so.nf2ff_boxes(freqs=other)
+    assert bh[0].shape[0] == 2 and max(np.abs(b).max() for b in bo) > 0
+    for a, b in zip(bh, bo):
+        assert rel_l2(a, b) < 1e-12
+    with pytest.raises(ValueError, match="above the recorder"):
+        sr.nf2ff_boxes(freqs=[9e9])
+
+
+def test_far_field_taken_at_the_s11_resonance(hip_lib, oracle_lib, tmp_path):
+    """Row a13 completed: the microstrip variant picks f_res from S11 and evaluates CalcNF2FF THERE
+    (solver_fdtd_openems_microstrip.py:407-433) — possible because the NF2FF faces are recorded in the time domain.
+    HIP vs oracle: same f_res, pattern frequency == f_res (the dip is below -10 dB), cuts within 1e-3; and the
+    dft-mode fallback (comb) snaps to its nearest recorded frequency and says so in f_pattern."""
+    s = pkg("solver_fdtd_hip")
+    P = pkg("params").PatchAntennaParams
+    p = P.from_user_units(frequency_ghz=2.45, er=4.3, h_mm=1.6, loss_tangent=0.02)
+    res = []
+    for lib, tag in ((hip_lib, "gpu"), (oracle_lib, "cpu")):
+        prep = s.prepare_hip_microstrip_patch(p, feed_direction=s.FeedDirection.NEG_X, boundary="MUR",
+                                              work_dir=str(tmp_path / tag), lib=lib)
+        assert prep.ok, prep.message
+        assert prep.variant == "microstrip"
+        prep.FDTD.NrTS = 9000
+        r = s.run_prepared_hip(prep, frequency_hz=p.frequency_hz, verbose=0)
+        assert r.ok, r.message
+        assert prep.FDTD.sim.nf2ff_mode == "record"
+        res.append(r)
+    g, c = res
+    assert g.s11_dB.min() < -10.0, f"no dip below -10 dB (min {g.s11_dB.min():.1f} dB): the resonance rule cannot be exercised"
+    assert g.f_res == c.f_res and g.f_res != p.frequency_hz
+    assert g.f_res == g.freq[np.argmin(g.s11_dB)]
+    assert g.f_pattern == g.f_res and c.f_pattern == c.f_res
+    lin = lambda d: 10.0 ** (np.asarray(d) / 20.0)
+    assert rel_l2(lin(g.intensity), lin(c.intensity)) < 1e-3 and rel_l2(g.s11, c.s11) < 1e-3
+    # dft-mode fallback: 21-point comb, the far field snaps to the nearest recorded frequency
+    prep = s.prepare_hip_microstrip_patch(p, feed_direction=s.FeedDirection.NEG_X, boundary="MUR",
+                                          work_dir=str(tmp_path / "comb"), nf2ff_mode="dft")
+    prep.FDTD.NrTS = 9000
+    r = s.run_prepared_hip(prep, frequency_hz=p.frequency_hz, verbose=0)
+    assert r.ok, r.message
+    comb = pkg("openems_api").nf2ff_comb(p.frequency_hz)
+    assert prep.FDTD.sim.nf2ff_mode == "dft" and prep.FDTD.sim.nf2ff_freqs.size == comb.size
+    assert r.f_res == g.f_res and r.f_pattern in comb and abs(r.f_pattern - r.f_res) <= 0.5 * np.diff(comb).max() * (1 + 1e-9)
+    assert rel_l2(lin(r.intensity), lin(g.intensity)) < 0.05
+
+
+def test_p2p_argument_and_state_checks(hip_lib):
+    """Mailbox transport misuse comes back as FDTD_E_* codes, not as device faults: attaching after the first step,
+    a neighbour blob that belongs to another grid, a zero self-test token."""
+    capi = pkg("_capi")
+    sims = [patch_sim(40, 36, 24, nr_ts=20, nf2ff=False) for _ in range(2)]
+    engs = [s.build(hip_lib, rank=r, world=2) for r, s in enumerate(sims)]
+    blobs = [e.p2p_export() for e in engs]
+    other = patch_sim(44, 36, 24, nr_ts=20, nf2ff=False).build(hip_lib, rank=1, world=2)
+    with pytest.raises(capi.FdtdError, match="another grid"):
+        engs[0].p2p_attach(None, other.p2p_export())
+    stepped = patch_sim(40, 36, 24, nr_ts=20, nf2ff=False).build(hip_lib, rank=0, world=2)
+    stepped.half_step(capi.PHASE_E); stepped.half_step(capi.PHASE_H)
+    with pytest.raises(capi.FdtdError, match="before the first timestep"):
+        stepped.p2p_attach(None, blobs[1])
+    engs[0].p2p_attach(None, blobs[1])
+    engs[1].p2p_attach(blobs[0], None)
+    with pytest.raises(capi.FdtdError, match="non-zero"):
+        engs[0].p2p_selftest(0)
+
+
+def test_tutorial_scene_gpu_equals_oracle(hip_lib, oracle_lib, tmp_path):
+    """The openEMS tutorial patch that the reference's test_openems.py:19-99 builds (tests/tutorial_scene.py), on the HIP
+    library and on the oracle: same stop step, S11(f) and port series to 1e-3 / 1e-4, the same dip inside 2.35-2.60 GHz,
+    D within 6-8 dBi, pattern at the dip within 1e-3."""
+    import tutorial_scene
+    g = tutorial_scene.build_and_run(hip_lib, str(tmp_path / "gpu"))
+    c = tutorial_scene.build_and_run(oracle_lib, str(tmp_path / "cpu"))
+    assert g["grid"] == c["grid"] and g["steps"] == c["steps"]
+    assert rel_l2(g["u"], c["u"]) < 1e-4 and rel_l2(g["i"], c["i"]) < 1e-4 and rel_l2(g["s11"], c["s11"]) < 1e-3
+    assert g["f_dip"] == c["f_dip"] and 2.35e9 <= g["f_dip"] <= 2.60e9 and g["dip_dB"] < -10.0
+    assert 6.0 <= 10 * np.log10(g["Dmax"]) <= 8.0 and abs(g["Dmax"] - c["Dmax"]) < 1e-6 * c["Dmax"]
+    assert rel_l2(g["E_norm"], c["E_norm"]) < 1e-3
