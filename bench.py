@@ -44,7 +44,6 @@ def main():
     ap.add_argument("--workload", default="NS")
     ap.add_argument("--ts-per-step", type=int, default=500)
     ap.add_argument("--cpml-cells", type=int, default=10)
-    ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "fused", "tile", "march"])
     ap.add_argument("--halo", default="auto", choices=["auto", "p2p", "rccl", "host"],
                     help="N > 1: halo transport (auto = P2P mailbox, then RCCL, then host copies)")
     ap.add_argument("--raw-operator", action="store_true", help="stream 12 coefficient arrays instead of class bytes")
@@ -88,8 +87,7 @@ def main():
     nts_total = (args.steps + args.warmup) * args.ts_per_step * 2 + 8
     sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=args.cpml_cells,
                           nr_ts=nts_total, nf2ff_freqs=[w.f0], use_classes=not args.raw_operator)
-    flags = {"auto": capi.FLAG_KERNEL_AUTO, "direct": capi.FLAG_KERNEL_DIRECT, "fused": capi.FLAG_KERNEL_FUSED, "tile": capi.FLAG_KERNEL_TILE, "march": capi.FLAG_KERNEL_MARCH}[args.kernel]
-    eng = sim.build(hip, rank=rank, world=world, device=local_rank, flags=flags)
+    eng = sim.build(hip, rank=rank, world=world, device=local_rank)
     comm = None
     if world > 1:
         # halo transport inside the library: P2P mailboxes (kernels push the halo planes over xGMI), else RCCL
@@ -132,10 +130,11 @@ def main():
     # length in which every main launch carries start / stop events (hipExtLaunchKernelGGL) = the dispatch's begin
     # and end timestamps, the interval a rocprofv3 kernel trace reports; nothing is subtracted.
     if sim.external_transport is not None:      # host transport: no in-library step loop to profile
+        run_steps(min(timesteps, 2000))         # the same second pass, so that every transport ends on the same timestep
         prof = capi.FdtdProfile(ms_total=elapsed * 1e3, ms_update_e=float("nan"), ms_update_h=float("nan"), steps=timesteps)
     else:
         prof = eng.run_profiled(min(timesteps, 2000))
-    roofline = roofline_block(args.workload, eng, prof, world, sim.external_transport is not None)
+    roofline = roofline_block(args.workload, eng, prof, world, sim.external_transport is not None, elapsed / timesteps * 1e3)
     finite = bool(np.isfinite(eng.get_field(0, 2)).all())
     # L2 norm of the first port's voltage series over every timestep stepped so far (rank-summed): identical for every
     # N and every halo transport, since the decomposed run is bit-identical to the single-slab run
@@ -201,15 +200,12 @@ def working_set_bytes(eng):
     return int(eng.nk) * int(eng.ny) * int(eng.nx) * (6 * 4 + 1)
 
 
-def roofline_block(workload, eng, prof, world, host_transport):
+def roofline_block(workload, eng, prof, world, host_transport, ms_timestep):
     own_cells = eng.nk * eng.ny * eng.nx
     algo_bytes = ALGO_BYTES_PER_CELL_HALFSTEP * own_cells
     ms_e, ms_h = prof.ms_update_e, prof.ms_update_h
-    if prof.fused:      # one launch does both half-steps: 72 algorithmic bytes per cell per launch
-        dom, ms_dom, algo_bytes = "step_fused", ms_e, 2 * algo_bytes
-    else:
-        dom = "update_E" if ms_e >= ms_h else "update_H"
-        ms_dom = max(ms_e, ms_h)
+    dom = "update_E" if ms_e >= ms_h else "update_H"
+    ms_dom = max(ms_e, ms_h)
     if host_transport or not (ms_dom == ms_dom and ms_dom > 0):
         # host halo transport: kernels are launched one half-step at a time, nothing to profile
         return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
@@ -226,12 +222,14 @@ def roofline_block(workload, eng, prof, world, host_transport):
            "ms_per_timestep_profiled": round(ms_ts, 5),
            # the 256 MiB Infinity Cache holds the whole working set of the smaller grids: their 'HBM' rate is a cache rate
            "resident": "infinity-cache" if ws < (240 << 20) else "hbm", "working_set_bytes": ws}
-    if not prof.fused and world == 1:
-        # the two main launches of a timestep cannot take longer than the timestep, and leave only launch gaps + the
-        # occasional DFT launch: a figure outside this band means the kernel timing is broken, not the kernel
-        ratio = (ms_e + ms_h) / ms_ts
+    if world == 1:
+        # against the UNPROFILED timestep of the timed region (the profiled pass pays for its events): the two main
+        # launches cannot take longer than the timestep, and on a grid that fills the chip they leave only the launch
+        # gaps and the occasional DFT launch.  A figure outside the band means the kernel timing is broken.
+        ratio = (ms_e + ms_h) / ms_timestep
+        out["ms_per_timestep"] = round(ms_timestep, 5)
         out["kernels_over_timestep"] = round(ratio, 4)
-        assert 0.80 < ratio <= 1.02, f"kernel durations {ms_e:.5f} + {ms_h:.5f} ms do not add up to the timestep {ms_ts:.5f} ms"
+        assert 0.5 < ratio <= 1.02, f"kernel durations {ms_e:.5f} + {ms_h:.5f} ms do not add up to the timestep {ms_timestep:.5f} ms"
     return out
 
 
@@ -248,7 +246,7 @@ def hbm_resident_point(capi, wl, sc, simm, hip, args, name="C3", steps=300):
     eng.run(steps)
     dt = time.perf_counter() - t0
     prof = eng.run_profiled(steps)
-    blk = roofline_block(name, eng, prof, 1, False)
+    blk = roofline_block(name, eng, prof, 1, False, dt / steps * 1e3)
     blk["workload"] = f"{name}: {w.grid.shape[0]}x{w.grid.shape[1]}x{w.grid.shape[2]} fixed scene, CPML-{args.cpml_cells}, {steps} timesteps"
     blk["value_mcells_s"] = round(w.grid.ncells * steps / dt / 1e6, 1)
     return blk
@@ -268,7 +266,7 @@ def pmc_traffic(workload, kernel, world):
     try:
         data = json.load(open(files[-1]))["per_launch_traffic"]
         for name, rec in data.items():
-            if kernel.replace("update_", "k_update_").replace("step_fused", "k_step_fused") in name:
+            if kernel.replace("update_", "k_update_") in name:
                 return round(rec["total_bytes"]), ("committed rocprofv3 --pmc passes, not measured in this run: "
                                                    + os.path.relpath(files[-1], ROOT))
     except (OSError, KeyError, ValueError):

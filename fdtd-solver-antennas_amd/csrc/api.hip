@@ -47,22 +47,15 @@ static hipError_t to_device(T** dst, const std::vector<T>& v) {
   return hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
 }
 
-// Per strip-plane source lists (CSR) for a tiling of `tys` rows per strip: a source at (k, j) is listed in every
-// strip-plane (s, kk) with kk in [k - dk, k] and rows [s*tys - dj .. ) covering j, i.e. dj = dk = 0 for the
-// two-pass kernels and 1 for the fused kernel, whose threads also compute row j+1 and plane k+1.
-static hipError_t build_source_lists(const fdtd_ctx* c, int tys, int nstrips, int dil, int2** d_rng, int** d_ids,
-                                     int* max_len = nullptr) {
+// Per strip-plane source lists (CSR) for a tiling of `tys` rows per strip: a source at (k, j) is listed in the
+// strip-plane that holds row j of plane k.
+static hipError_t build_source_lists(const fdtd_ctx* c, int tys, int nstrips, int2** d_rng, int** d_ids) {
   const int nk = c->d.nk;
   std::vector<std::vector<int>> lists((size_t)nk * nstrips);
   for (size_t e = 0; e < c->h_src_off.size(); ++e) {
     const int off = c->h_src_off[e];
     const int k = off / c->plane, j = (off - k * c->plane) / c->P;
-    for (int kk = k - dil; kk <= k; ++kk)
-      for (int jj = j - dil; jj <= j; ++jj) {
-        if (kk < 0 || jj < 0) continue;
-        auto& l = lists[(size_t)kk * nstrips + jj / tys];
-        if (l.empty() || l.back() != (int)e) l.push_back((int)e);
-      }
+    lists[(size_t)k * nstrips + j / tys].push_back((int)e);
   }
   std::vector<int2> rng(lists.size());
   std::vector<int> ids;
@@ -70,7 +63,6 @@ static hipError_t build_source_lists(const fdtd_ctx* c, int tys, int nstrips, in
     rng[q].x = (int)ids.size();
     ids.insert(ids.end(), lists[q].begin(), lists[q].end());
     rng[q].y = (int)ids.size();
-    if (max_len && (int)lists[q].size() > *max_len) *max_len = (int)lists[q].size();
   }
   hipFree(*d_rng); hipFree(*d_ids); *d_rng = nullptr; *d_ids = nullptr;
   hipError_t err = hipMalloc(d_rng, rng.size() * sizeof(int2));
@@ -87,7 +79,7 @@ static hipError_t build_source_lists(const fdtd_ctx* c, int tys, int nstrips, in
 int upload_metric_tables(fdtd_ctx* c, const float* emet, const float* hmet) {
   const int nx = c->d.nx, ny = c->d.ny, nk = c->d.nk, P = c->P;
   auto al4 = [](int v) { return (v + 3) / 4 * 4; };
-  // +4 floats of zero slack per table: the fused kernel reads the entries of cell i0+4, row j+1, plane k+1
+  // +4 floats of zero slack per table
   const int sx_ = P + 4, sy_ = al4(ny) + 4, sz_ = al4(nk) + 4;
   const int seg = sx_ + sy_ + sz_;
   std::vector<float> host((size_t)6 * seg, 0.f);
@@ -185,18 +177,10 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   // six field arrays + class bytes vs the 256 MiB Infinity Cache
   p.nt = ((size_t)c->nloc * (6 * sizeof(float) + 1) > (size_t)200 << 20) ? 1 : 0;
   choose_tiling(c);
-  if (const char* ts = getenv("FDTD_TILE_SHAPE")) {
-    const int v = (int)strtol(ts, nullptr, 16);
-    if (v == 0x88 || v == 0x48 || v == 0x84 || v == 0x44) c->tile_shape = v;
-  }
   p.sweep_rev = getenv("FDTD_NO_SWEEP_REV") ? 0 : 1;
   if (const char* v = getenv("FDTD_OCC_E")) c->occ_e = std::max(0, std::min(16, atoi(v)));
   if (const char* v = getenv("FDTD_OCC_H")) c->occ_h = std::max(0, std::min(16, atoi(v)));
-  if (const char* kc = getenv("FDTD_MARCH_KC")) {
-    const int v = atoi(kc);
-    if (v >= 1 && v <= 4096) c->march_kc = v;
-  }
-  p.src_rng = nullptr; p.src_ids = nullptr; p.src_rng2 = nullptr; p.src_ids2 = nullptr; p.src_rng3 = nullptr; p.src_ids3 = nullptr; p.src_rng4 = nullptr; p.src_ids4 = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
+  p.src_rng = nullptr; p.src_ids = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
   p.sig = c->sig; p.nsig = 0;
   p.probes = c->d_probe; p.nprobe = 0; p.max_steps = d->max_steps;
   *out = c;
@@ -220,9 +204,7 @@ void fdtd_destroy(fdtd_ctx* c) {
   }
   for (int b = 0; b < c->nbox; ++b) { hipFree(c->box[b].acc); hipFree(c->box[b].rec); }
   hipFree(c->d_probe); hipFree(c->d_box); hipFree(c->tw_v); hipFree(c->tw_i);
-  hipFree(c->d_energy); hipFree(c->src_rng); hipFree(c->src_ids); hipFree(c->src_rng2); hipFree(c->src_ids2);
-  hipFree(c->src_rng3); hipFree(c->src_ids3); hipFree(c->src_rng4); hipFree(c->src_ids4);
-  for (int n = 0; n < 6; ++n) { hipFree(c->fieldbase2[n]); hipFree(c->psi2[n]); }
+  hipFree(c->d_energy); hipFree(c->src_rng); hipFree(c->src_ids);
   if (c->peer_lo && c->peer_lo_ipc) hipIpcCloseMemHandle(c->peer_lo);
   if (c->peer_hi && c->peer_hi_ipc) hipIpcCloseMemHandle(c->peer_hi);
   hipFree(c->mbox);
@@ -263,7 +245,7 @@ int fdtd_set_operator_classes(fdtd_ctx* c, const uint8_t* ecls, int ncls, const 
   const size_t n = 3 * c->nloc;
   for (size_t q = 0; q < (size_t)3 * nk * ny * nx; ++q)
     if (ecls[q] >= ncls) return fdtd_fail(c, FDTD_E_ARG, "class %d >= ncls %d", (int)ecls[q], ncls);
-  const size_t n_alloc = n + (size_t)c->plane + 64;   // slack: the fused kernel reads the class bytes of plane k+1
+  const size_t n_alloc = n + 64;
   if (!c->ecls) HIPCK(c, hipMalloc(&c->ecls, n_alloc));
   HIPCK(c, hipMemset(c->ecls, 0, n_alloc));
   // One byte per CELL when the scene has <= 256 distinct (cx, cy, cz) class triples (1 B instead of
@@ -392,15 +374,13 @@ int fdtd_set_cpml(fdtd_ctx* c, const int32_t* sx, const int32_t* sy, const int32
         const int a = (comp + 1 + w) % 3;
         float* ptr = nullptr;
         // allocate at least 16 B so interior kernels always hold a valid pointer
-        const size_t bytes = psz[a] * sizeof(float) + 64;   // slack for the fused kernel's o+4 reads
+        const size_t bytes = psz[a] * sizeof(float) + 64;
         HIPCK(c, hipMalloc(&ptr, bytes));
         HIPCK(c, hipMemset(ptr, 0, bytes));
         c->psi[(eh * 3 + comp) * 2 + w] = ptr;
         (eh ? c->p.psiH : c->p.psiE)[comp][w] = ptr;
       }
   c->have_cpml = (nsx + nsy + nsz) > 0;
-  c->psi_bytes[0] = psz[0] * sizeof(float) + 64; c->psi_bytes[1] = psz[1] * sizeof(float) + 64; c->psi_bytes[2] = psz[2] * sizeof(float) + 64;
-  c->fused_ready = false;
   return FDTD_OK;
 }
 
@@ -467,9 +447,8 @@ int fdtd_add_source(fdtd_ctx* c, int n, const int64_t* idx, const int8_t* comp, 
   HIPCK(c, to_device(&c->src_comp, c->h_src_comp));
   HIPCK(c, to_device(&c->src_amp, c->h_src_amp));
   HIPCK(c, to_device(&c->src_delay, c->h_src_delay));
-  HIPCK(c, build_source_lists(c, c->p.tys, c->p.nstrips, 0, &c->src_rng, &c->src_ids));
+  HIPCK(c, build_source_lists(c, c->p.tys, c->p.nstrips, &c->src_rng, &c->src_ids));
   c->p.src_rng = c->src_rng; c->p.src_ids = c->src_ids;
-  c->fused_ready = false;
   c->p.nsrc = c->nsrc; c->p.src_off = c->src_off; c->p.src_comp = c->src_comp; c->p.src_amp = c->src_amp;
   c->p.src_delay = c->src_delay;
   return FDTD_OK;
@@ -718,86 +697,6 @@ static bool sources_fusable(const fdtd_ctx* c) {
   return true;
 }
 
-static bool fused_eligible(const fdtd_ctx* c) {
-  return c->d.world == 1 && !c->any_mur && c->have_op && !c->raw_op;
-}
-
-// Second buffer set for the one-pass kernel (fields + psi_E), dilated source flags.
-static int ensure_fused(fdtd_ctx* c) {
-  if (c->fused_ready) return FDTD_OK;
-  const size_t fbytes = (size_t)c->plane * (c->d.nk + 2) * sizeof(float);
-  for (int n = 0; n < 6; ++n) {
-    if (!c->fieldbase2[n]) {
-      HIPCK(c, hipMalloc(&c->fieldbase2[n], fbytes));
-      HIPCK(c, hipMemset(c->fieldbase2[n], 0, fbytes));
-    }
-  }
-  // which of the two allocations is "current" is tracked by p.V/p.I; the partner is the other one
-  for (int n = 0; n < 3; ++n) {
-    float* a = c->fieldbase[n] + c->plane; float* b = c->fieldbase2[n] + c->plane;
-    c->p.Vn[n] = (c->p.V[n] == a) ? b : a;
-    a = c->fieldbase[3 + n] + c->plane; b = c->fieldbase2[3 + n] + c->plane;
-    c->p.In[n] = (c->p.I[n] == a) ? b : a;
-  }
-  for (int comp = 0; comp < 3; ++comp)
-    for (int w = 0; w < 2; ++w) {
-      const int q = comp * 2 + w, ax = (comp + 1 + w) % 3;
-      hipFree(c->psi2[q]); c->psi2[q] = nullptr;
-      const size_t bytes = c->have_cpml ? c->psi_bytes[ax] : 64;
-      HIPCK(c, hipMalloc(&c->psi2[q], bytes));
-      HIPCK(c, hipMemset(c->psi2[q], 0, bytes));
-      c->p.psiEn[comp][w] = c->psi2[q];
-      if (!c->have_cpml) c->p.psiE[comp][w] = c->psi2[q];
-    }
-  choose_tiling_fused(c);
-  int max_len = 0;
-  HIPCK(c, build_source_lists(c, c->p.tys2, c->p.nstrips2, 1, &c->src_rng2, &c->src_ids2, &max_len));
-  if (max_len > FDTD_BLOCK)
-    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "fused kernel: %d source edges in one strip-plane (limit %d)", max_len, FDTD_BLOCK);
-  c->p.src_rng2 = c->src_rng2; c->p.src_ids2 = c->src_ids2;
-  // per-tile source lists (LDS-tile kernel: 3-D tiles; z-marching kernel: tile columns)
-  auto tile_lists = [&](size_t ntiles, auto&& tiles_of, const char* what, int2** d_rng, int** d_ids) -> int {
-    std::vector<std::vector<int>> lists(ntiles);
-    std::vector<int> tl;
-    for (size_t e = 0; e < c->h_src_off.size(); ++e) {
-      const int off = c->h_src_off[e];
-      const int k = off / c->plane, j = (off - k * c->plane) / c->P, i = off - k * c->plane - j * c->P;
-      tl.clear();
-      tiles_of(i / 4, j, k, tl);
-      for (int t : tl) lists[t].push_back((int)e);
-    }
-    std::vector<int2> rng(lists.size());
-    std::vector<int> ids;
-    int mx = 0;
-    for (size_t q = 0; q < lists.size(); ++q) {
-      rng[q].x = (int)ids.size();
-      ids.insert(ids.end(), lists[q].begin(), lists[q].end());
-      rng[q].y = (int)ids.size();
-      mx = std::max(mx, (int)lists[q].size());
-    }
-    if (mx > FDTD_BLOCK) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "%s kernel: %d source edges in one tile (limit %d)", what, mx, FDTD_BLOCK);
-    hipFree(*d_rng); hipFree(*d_ids); *d_rng = nullptr; *d_ids = nullptr;
-    HIPCK(c, hipMalloc(d_rng, rng.size() * sizeof(int2)));
-    HIPCK(c, hipMemcpy(*d_rng, rng.data(), rng.size() * sizeof(int2), hipMemcpyHostToDevice));
-    HIPCK(c, hipMalloc(d_ids, std::max<size_t>(ids.size(), 1) * sizeof(int)));
-    if (!ids.empty()) HIPCK(c, hipMemcpy(*d_ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
-    return FDTD_OK;
-  };
-  {
-    int ntx, nty, ntz, kc, r;
-    tile_counts(c, ntx, nty, ntz);
-    if ((r = tile_lists((size_t)ntx * nty * ntz, [&](int gx, int j, int k, std::vector<int>& o) { tiles_of_cell(c, gx, j, k, o); },
-                        "tile", &c->src_rng3, &c->src_ids3))) return r;
-    c->p.src_rng3 = c->src_rng3; c->p.src_ids3 = c->src_ids3;
-    march_counts(c, ntx, nty, ntz, kc);
-    if ((r = tile_lists((size_t)ntx * nty * ntz, [&](int gx, int j, int k, std::vector<int>& o) { march_tiles_of_cell(c, gx, j, k, o); },
-                        "march", &c->src_rng4, &c->src_ids4))) return r;
-    c->p.src_rng4 = c->src_rng4; c->p.src_ids4 = c->src_ids4;
-  }
-  c->fused_ready = true;
-  return FDTD_OK;
-}
-
 struct ProfEvents {
   std::vector<hipEvent_t> e0, e1, h0, h1;
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -874,21 +773,12 @@ static int phase_H(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
   return FDTD_OK;
 }
 
-static int step_loop_fused(fdtd_ctx* c, int nsteps, struct ProfEvents* pe);
 static int step_loop_p2p(fdtd_ctx* c, int nsteps, struct ProfEvents* pe);
 static int p2p_check(fdtd_ctx* c);
 
-static bool one_pass_mode(unsigned kmode) {
-  return kmode == FDTD_FLAG_KERNEL_FUSED || kmode == FDTD_FLAG_KERNEL_TILE || kmode == FDTD_FLAG_KERNEL_MARCH;
-}
-
 static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
-  const unsigned kmode = c->d.flags & FDTD_FLAG_KERNEL_MASK;
-  if (one_pass_mode(kmode) && !fused_eligible(c))
-    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "fused kernel needs a single slab, a class operator and no Mur faces");
-  // AUTO currently resolves to the two-pass kernels (faster on MI355X as measured, profiles/r01); the
-  // one-pass kernel is opt-in until it shares neighbours through LDS.
-  if (one_pass_mode(kmode)) return step_loop_fused(c, nsteps, pe);
+  if ((c->d.flags & FDTD_FLAG_KERNEL_MASK) > FDTD_FLAG_KERNEL_DIRECT)
+    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "kernel selection %u: the one-pass variants of ABI v1 were removed (measured slower than the two-pass kernels on every workload)", c->d.flags & FDTD_FLAG_KERNEL_MASK);
   if (c->p.p2p) return step_loop_p2p(c, nsteps, pe);
   const bool multi = c->d.world > 1;
   if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_p2p_attach (mailbox transport), fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
@@ -932,35 +822,6 @@ static int step_loop_p2p(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
     c->step++;
   }
   if (nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);   // flush the last step's I-probes
-  HIPCK(c, hipGetLastError());
-  return FDTD_OK;
-}
-
-// One launch per step: new V, I (and psi_E) go to the partner buffers, then the roles swap.  The probe block
-// of launch n samples both probe kinds of step n-1; the last step is flushed by stand-alone launches.
-static int step_loop_fused(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
-  int r = ensure_fused(c);
-  if (r) return r;
-  hipStream_t s = c->stream;
-  for (int n = 0; n < nsteps; ++n) {
-    const long long step = c->step;
-    if (pe) HIPCK(c, hipEventRecord(pe->e0[n], s));
-    const unsigned kmode = c->d.flags & FDTD_FLAG_KERNEL_MASK;
-    if (kmode == FDTD_FLAG_KERNEL_MARCH) launch_step_march(c, step, true, s);
-    else if (kmode == FDTD_FLAG_KERNEL_TILE) launch_step_tile(c, step, true, s);
-    else launch_step_fused(c, step, true, s);
-    if (pe) { HIPCK(c, hipEventRecord(pe->e1[n], s)); HIPCK(c, hipEventRecord(pe->h0[n], s)); HIPCK(c, hipEventRecord(pe->h1[n], s)); }
-    for (int q = 0; q < 3; ++q) { std::swap(c->p.V[q], c->p.Vn[q]); std::swap(c->p.I[q], c->p.In[q]); }
-    for (int comp = 0; comp < 3; ++comp)
-      for (int w = 0; w < 2; ++w) std::swap(c->p.psiE[comp][w], c->p.psiEn[comp][w]);
-    launch_dft(c, FDTD_KIND_V, step, s);
-    launch_dft(c, FDTD_KIND_I, step, s);
-    c->step++;
-  }
-  if (nsteps > 0) {
-    launch_post(c, FDTD_KIND_V, c->step - 1, false, s);
-    launch_post(c, FDTD_KIND_I, c->step - 1, false, s);
-  }
   HIPCK(c, hipGetLastError());
   return FDTD_OK;
 }
@@ -1014,20 +875,18 @@ int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
     hipEventElapsedTime(&ms, pe.t0, pe.t1);
     memset(out, 0, sizeof(*out));
     out->ms_total = ms; out->steps = nsteps;
-    // Two-pass kernels: every main launch carried its own start / stop events (hipExtLaunchKernelGGL), which take the
-    // dispatch's begin and end timestamps — the interval a kernel trace reports, no event-packet time inside, nothing
-    // to calibrate away.  (One-pass kernels are bracketed by ordinary event records.)
+    // Every main launch carried its own start / stop events (hipExtLaunchKernelGGL), which take the dispatch's begin
+    // and end timestamps — the interval a kernel trace reports, no event-packet time inside, nothing to calibrate away.
     double se = 0, sh = 0;
-    const bool one_pass = one_pass_mode(c->d.flags & FDTD_FLAG_KERNEL_MASK);
     for (int n = 0; n < nsteps; ++n) {
       if (hipEventElapsedTime(&ms, pe.e0[n], pe.e1[n]) == hipSuccess) se += ms;
-      if (!one_pass && hipEventElapsedTime(&ms, pe.h0[n], pe.h1[n]) == hipSuccess) sh += ms;
+      if (hipEventElapsedTime(&ms, pe.h0[n], pe.h1[n]) == hipSuccess) sh += ms;
     }
     (void)hipGetLastError();
     out->ms_event_overhead = 0.0;
     out->ms_update_e = se / nsteps;
-    out->ms_update_h = one_pass ? 0.0 : sh / nsteps;
-    out->fused = one_pass ? 1 : 0;
+    out->ms_update_h = sh / nsteps;
+    out->fused = 0;
     out->launches_e = out->launches_h = nsteps;
   }
   destroy_all();
@@ -1125,6 +984,21 @@ static_assert(sizeof(P2pBlob) <= 128, "blob must fit the 128-byte exchange buffe
 
 static size_t p2p_floats(const fdtd_ctx* c) { return (size_t)8 * c->plane; }
 
+// The mailbox is only ever touched with system-scope (write-through / cache-bypassing) accesses — also when it is zeroed,
+// so that no plain fill leaves copies of its lines in some XCD's L2 for a later mailbox load to find.
+__global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_zero(float* mbox, const size_t n4, unsigned* ctl, const int nctl) {
+  const size_t t = (size_t)blockIdx.x * FDTD_BLOCK + threadIdx.x;
+  if (t < n4) st4_sys(mbox + 4 * t, make_float4(0.f, 0.f, 0.f, 0.f));
+  if (ctl && t < (size_t)nctl) __hip_atomic_store(ctl + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// zero the halo planes (and, with `ctl`, the 64 control words) of this context's own mailbox, on its stream
+static void p2p_zero(fdtd_ctx* c, bool ctl) {
+  const size_t n4 = (size_t)2 * c->plane;   // 8 planes of floats = 2 * plane float4 groups
+  hipLaunchKernelGGL(k_p2p_zero, dim3((unsigned)((n4 + FDTD_BLOCK - 1) / FDTD_BLOCK)), dim3(FDTD_BLOCK), 0, c->stream,
+                     (float*)c->mbox, n4, ctl ? (unsigned*)((float*)c->mbox + (size_t)8 * c->plane) : nullptr, 64);
+}
+
 static int p2p_alloc(fdtd_ctx* c) {
   if (c->mbox) return FDTD_OK;
   HIPCK(c, hipSetDevice(c->d.device));
@@ -1140,8 +1014,8 @@ static int p2p_alloc(fdtd_ctx* c) {
     c->mbox_fine = true;
   }
   if (getenv("FDTD_P2P_DEBUG")) fprintf(stderr, "[fdtd-hip] rank %d mailbox: %zu bytes, %s device memory\n", c->d.rank, c->mbox_bytes, c->mbox_fine ? "fine-grained" : "coarse-grained");
-  HIPCK(c, hipMemset(c->mbox, 0, c->mbox_bytes));
-  HIPCK(c, hipDeviceSynchronize());   // the kernels run on a non-blocking stream: the zeros must be there first
+  p2p_zero(c, true);
+  HIPCK(c, hipStreamSynchronize(c->stream));   // the zeros must be there before a neighbour maps and writes the mailbox
   return FDTD_OK;
 }
 
@@ -1281,7 +1155,8 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_selftest_post(const DevParam
   }
 }
 
-// result[0]: blocks that timed out waiting for a token; result[1]: float4 groups that read back wrong
+// result[0]: blocks that timed out waiting for a token; result[1]: float4 groups that read back wrong;
+// result[2]: index (slot * n4 + t, +2^30 for the H mailbox) of one wrong group, result[3]: its first word as read
 __global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_selftest_verify(const DevParams p, const unsigned token, unsigned* result) {
   __shared__ int s_ok;
   if (threadIdx.x == 0) {
@@ -1306,13 +1181,17 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_selftest_verify(const DevPar
   for (unsigned slot = 0; slot < 4u; ++slot) {
     if (p.mb_in_E) {   // written by the upper neighbour as ITS E-down halo (dir 0)
       const float4 g = ld4_sys(p.mb_in_E + (size_t)slot * p.plane + 4u * t), w = p2p_pattern(token, 0u, slot, t);
-      bad += (__float_as_uint(g.x) != __float_as_uint(w.x)) | (__float_as_uint(g.y) != __float_as_uint(w.y)) |
-             (__float_as_uint(g.z) != __float_as_uint(w.z)) | (__float_as_uint(g.w) != __float_as_uint(w.w));
+      const unsigned b = (__float_as_uint(g.x) != __float_as_uint(w.x)) | (__float_as_uint(g.y) != __float_as_uint(w.y)) |
+                         (__float_as_uint(g.z) != __float_as_uint(w.z)) | (__float_as_uint(g.w) != __float_as_uint(w.w));
+      if (b) { result[2] = slot * n4 + t; result[3] = __float_as_uint(g.x); }
+      bad += b;
     }
     if (p.mb_in_H) {   // written by the lower neighbour as ITS H-up halo (dir 1)
       const float4 g = ld4_sys(p.mb_in_H + (size_t)slot * p.plane + 4u * t), w = p2p_pattern(token, 1u, slot, t);
-      bad += (__float_as_uint(g.x) != __float_as_uint(w.x)) | (__float_as_uint(g.y) != __float_as_uint(w.y)) |
-             (__float_as_uint(g.z) != __float_as_uint(w.z)) | (__float_as_uint(g.w) != __float_as_uint(w.w));
+      const unsigned b = (__float_as_uint(g.x) != __float_as_uint(w.x)) | (__float_as_uint(g.y) != __float_as_uint(w.y)) |
+                         (__float_as_uint(g.z) != __float_as_uint(w.z)) | (__float_as_uint(g.w) != __float_as_uint(w.w));
+      if (b) { result[2] = (1u << 30) + slot * n4 + t; result[3] = __float_as_uint(g.x); }
+      bad += b;
     }
   }
   if (bad) atomicAdd(result + 1, bad);
@@ -1325,16 +1204,16 @@ int fdtd_p2p_selftest(fdtd_ctx* c, unsigned token) {
   if (token == 0u) return fdtd_fail(c, FDTD_E_ARG, "p2p self-test token must be non-zero");
   HIPCK(c, hipSetDevice(c->d.device));
   unsigned* d_res = nullptr;
-  HIPCK(c, hipMalloc(&d_res, 2 * sizeof(unsigned)));
-  HIPCK(c, hipMemsetAsync(d_res, 0, 2 * sizeof(unsigned), c->stream));   // the context's stream is non-blocking: keep everything on it
+  HIPCK(c, hipMalloc(&d_res, 4 * sizeof(unsigned)));
+  HIPCK(c, hipMemsetAsync(d_res, 0, 4 * sizeof(unsigned), c->stream));   // the context's stream is non-blocking: keep everything on it
   const unsigned nb = (unsigned)((c->plane / 4 + FDTD_BLOCK - 1) / FDTD_BLOCK);
   hipLaunchKernelGGL(k_p2p_selftest_post, dim3(nb), dim3(FDTD_BLOCK), 0, c->stream, c->p, token);
   hipLaunchKernelGGL(k_p2p_selftest_verify, dim3(nb), dim3(FDTD_BLOCK), 0, c->stream, c->p, token, d_res);
-  unsigned res[2] = {0, 0};
+  unsigned res[4] = {0, 0, 0, 0};
   hipError_t e = hipMemcpyAsync(res, d_res, sizeof(res), hipMemcpyDeviceToHost, c->stream);
   // all neighbours' pattern stores into THIS mailbox were acknowledged before their tokens arrived: restore the zeros
   // the first timestep expects (the halo of "step -1" is the zero initial field), leave flags and counters alone
-  if (e == hipSuccess) e = hipMemsetAsync(c->mbox, 0, p2p_floats(c) * sizeof(float), c->stream);
+  if (e == hipSuccess) p2p_zero(c, false);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   hipFree(d_res);
   HIPCK(c, e);
@@ -1345,8 +1224,9 @@ int fdtd_p2p_selftest(fdtd_ctx* c, unsigned token) {
                      token, slots[0], slots[1]);
   }
   if (res[1])
-    return fdtd_fail(c, FDTD_E_DEVICE, "p2p self-test: %u of %u 16-byte halo groups read back wrong although the neighbour's token arrived (payload stores do not reach this mailbox in order)",
-                     res[1], (unsigned)(c->plane / 4) * 4u * ((c->p.mb_in_E ? 1u : 0u) + (c->p.mb_in_H ? 1u : 0u)));
+    return fdtd_fail(c, FDTD_E_DEVICE, "p2p self-test: %u of %u 16-byte halo groups read back wrong although the neighbour's token arrived (e.g. group %u of the %s mailbox reads %#x; %s device memory): payload stores do not reach this mailbox intact and in order",
+                     res[1], (unsigned)(c->plane / 4) * 4u * ((c->p.mb_in_E ? 1u : 0u) + (c->p.mb_in_H ? 1u : 0u)),
+                     res[2] & ((1u << 30) - 1u), (res[2] >> 30) ? "H" : "E", res[3], c->mbox_fine ? "fine-grained" : "coarse-grained");
   return FDTD_OK;
 }
 
@@ -1360,7 +1240,7 @@ int fdtd_p2p_detach(fdtd_ctx* c) {
   c->peer_lo = c->peer_hi = nullptr; c->peer_lo_ipc = c->peer_hi_ipc = false;
   DevParams& p = c->p;
   p.p2p = 0; p.mb_in_E = p.mb_in_H = p.mb_out_E = p.mb_out_H = nullptr; p.fl_out_E = p.fl_out_H = nullptr;
-  if (c->mbox) { HIPCK(c, hipMemset(c->mbox, 0, c->mbox_bytes)); HIPCK(c, hipDeviceSynchronize()); }
+  if (c->mbox) { p2p_zero(c, true); HIPCK(c, hipStreamSynchronize(c->stream)); }
   return FDTD_OK;
 }
 
@@ -1406,7 +1286,6 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
     if (loop) { if (c->comm) return fdtd_fail(c, FDTD_E_ARG, "loopback: linked and RCCL transports are exclusive"); continue; }
     if (c->d.world != n || c->d.rank != r || c->comm) return fdtd_fail(c, FDTD_E_ARG, "fdtd_run_linked: contexts must be ranks 0..n-1 of a world of n without an RCCL communicator");
     if (!c->p.p2p && ((r > 0 && c->link_lo != ctxs[r - 1]) || (r < n - 1 && c->link_hi != ctxs[r + 1]))) return fdtd_fail(c, FDTD_E_STATE, "fdtd_run_linked: call fdtd_link (or fdtd_p2p_attach) on every adjacent pair first");
-    if (one_pass_mode(c->d.flags & FDTD_FLAG_KERNEL_MASK)) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "one-pass kernels are single-slab");
   }
   const bool multi = n > 1 || (ctxs[0]->d.flags & FDTD_FLAG_LOOPBACK);
   if (ctxs[0]->p.p2p) {   // mailbox transport between contexts of this process: interleave the ranks' launches

@@ -46,8 +46,6 @@ struct DevParams {
   int nloc;   // nk * plane
   float* V[3];               // current fields (local plane 0; ghost planes at -plane and +nk*plane)
   float* I[3];
-  float* Vn[3];              // fused one-pass kernel: next-step buffers (ping-pong), else null
-  float* In[3];
   // operator: raw arrays [3][nk*plane] or class bytes + LUT + 1-D metric tables
   const float* vv; const float* vi; const float* ii; const float* iv;
   const uint8_t* ecls;       // class mode: [3][nloc] one byte per edge; packed mode: [nloc] one byte per cell
@@ -62,13 +60,6 @@ struct DevParams {
   const float* xc_tab;       // [E-loc/H-loc][b, c, 1/kappa][XC_MAX]: the x-layer cells' coefficients in psi-slot order (null: more than XC_MAX)
   float* psiE[3][2];
   float* psiH[3][2];
-  float* psiEn[3][2];        // fused kernel: next-step psi_E (ping-pong); psi_H is updated in place
-  const int2* src_rng3;      // LDS-tile kernel: sources computed by the threads of tile id
-  const int* src_ids3;
-  const int2* src_rng4;      // z-marching kernel: sources inside tile column id (xy footprint incl. feeders, planes kb..ke)
-  const int* src_ids4;
-  const int2* src_rng2;      // fused kernel tiling: sources in rows [j0, j0+rows] x planes [k, k+1] of a strip-plane
-  const int* src_ids2;
   // launch tiling: a block = 256 threads = 1024 consecutive x-cells of one strip of `tys` rows in one plane
   int tys, nbs, nstrips;
   FastDiv fd_nbs, fd_P4;     // dividers for the block / thread decode
@@ -85,8 +76,7 @@ struct DevParams {
   unsigned* p2p_cnt;         // local arrival counters [2]
   int* p2p_err;              // set when a halo wait timed out
   unsigned long long p2p_limit;   // wall-clock ticks a halo wait may last (10 s)
-  int tys2, nbs2, nstrips2;
-  int nt;                    // 1: non-temporal stores for the field outputs (working set beyond the Infinity Cache)  // tiling of the fused kernel (blocks of 4 x 63 owner groups)
+  int nt;                    // 1: non-temporal stores for the field outputs (working set beyond the Infinity Cache)
   // fused soft sources (update_E) and probes (extra block of update_E / update_H)
   const int2* src_rng;       // [nk][nstrips]: range into src_ids of the sources inside that strip-plane
   const int* src_ids;
@@ -106,21 +96,12 @@ struct fdtd_ctx {
   int P = 0, plane = 0;
   size_t nloc = 0;               // nk*plane
   float* fieldbase[6] = {};      // allocations incl. ghosts
-  float* fieldbase2[6] = {};     // ping-pong partner (fused kernel), allocated on first fused run
-  float* psi2[6] = {};           // ping-pong partner of the six psi_E arrays
-  int2* src_rng2 = nullptr; int* src_ids2 = nullptr;
-  int2* src_rng3 = nullptr; int* src_ids3 = nullptr;
-  int2* src_rng4 = nullptr; int* src_ids4 = nullptr;
   // P2P mailbox transport
   void* mbox = nullptr; size_t mbox_bytes = 0;     // my mailbox allocation
   bool mbox_fine = false;                          // fine-grained (system-coherent) device memory
   void* peer_lo = nullptr; void* peer_hi = nullptr; // neighbours' mailboxes (IPC mappings or in-process pointers)
   bool peer_lo_ipc = false, peer_hi_ipc = false;
   int occ_e = 0, occ_h = 0;      // cap on resident blocks per CU of update_E / update_H (0: none); $FDTD_OCC_E / $FDTD_OCC_H
-  int march_kc = 0;              // z-marching kernel: planes per chunk ($FDTD_MARCH_KC, default 10)
-  bool fused_ready = false;
-  int tile_shape = 0x88;         // LDS-tile kernel: (TY << 4) | TZ threads; $FDTD_TILE_SHAPE = 88 | 48 | 84 | 44
-  size_t psi_bytes[3] = {64, 64, 64};
   float *vv = nullptr, *vi = nullptr, *ii = nullptr, *iv = nullptr;
   uint8_t* ecls = nullptr;
   float2* lut = nullptr;
@@ -181,16 +162,5 @@ void launch_mur(fdtd_ctx* c, int mode, hipStream_t s);
 void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_t s);   // stand-alone sources + probes
 void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);   // running DFT or time-domain recording of the boxes
 void launch_rec_dft(const float* rec, long npts, int ns, int nfreq, const double* d_tw, double* d_out, hipStream_t s);
-// fused.hip: one launch = E half-step + H half-step of all owned planes, current -> next buffers
-void launch_step_fused(fdtd_ctx* c, long long step, bool probe_block, hipStream_t s);
-void choose_tiling_fused(fdtd_ctx* c);
-// tile.hip: one-pass kernel with an LDS-shared E tile
-void launch_step_tile(fdtd_ctx* c, long long step, bool probe_block, hipStream_t s);
-void tile_counts(const fdtd_ctx* c, int& ntx, int& nty, int& ntz);
-void tiles_of_cell(const fdtd_ctx* c, int gx, int j, int k, std::vector<int>& out);
-// march.hip: one-pass kernel, xy tiles marching through z
-void launch_step_march(fdtd_ctx* c, long long step, bool probe_block, hipStream_t s);
-void march_counts(const fdtd_ctx* c, int& ntx, int& nty, int& ntz, int& kc);
-void march_tiles_of_cell(const fdtd_ctx* c, int gx, int j, int k, std::vector<int>& out);
 void launch_energy(fdtd_ctx* c, hipStream_t s);
 void choose_tiling(fdtd_ctx* c);

@@ -1,4 +1,4 @@
-// kernel_common.hpp — device helpers shared by kernels.hip (two-pass leapfrog) and fused.hip (one-pass).
+// kernel_common.hpp — device helpers of the update kernels (kernels.hip) and of the mailbox self-test (api.hip).
 #pragma once
 #include "fdtd_ctx.h"
 
@@ -71,12 +71,16 @@ __device__ __forceinline__ void decode_block_fd(const FastDiv& fd_ps, const Fast
 typedef float v4f_sys __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld4_sys(const float* q) {
   v4f_sys r;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(q) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(q) : "memory");   // early clobber: the destination never shares registers with the address
   return make_float4(r.x, r.y, r.z, r.w);
 }
+// The s_nop is part of the instruction's contract here: a vector-memory store of more than 64 bits reads its data
+// registers AFTER issue, and a VALU write to them in the next wait states corrupts what the later lanes store (hipcc pads
+// its own stores; it cannot see into an asm statement).  Found by the data-path self-test of the mailbox transport: the
+// last 64 bytes of every 256 of one plane arrived with a compiler temporary (0 / 1) in their first word.
 __device__ __forceinline__ void st4_sys(float* q, const float4& v) {
   const v4f_sys t = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(q), "v"(t) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(q), "v"(t) : "memory");
 }
 // One lane per wave polls the flag until it reaches `need` (bounded: `limit` ticks of the wall clock = 10 s, then the
 // error word is set and the wave goes on with whatever the mailbox holds; once the error word is set no wait spins).  The mailbox loads that follow are issued after

@@ -321,7 +321,7 @@ int fdtd_build_operator(fdtd_ctx* c, const double* dx, const double* dy, const d
     { int r = collect_sorted(c, 1, nullptr, cls.p, ncell, ncell, triples, packed); if (r) return r; }
     if (!packed && 3 * c->nloc >= ((size_t)1 << 31))
       return fdtd_fail(c, FDTD_E_UNSUPPORTED, "per-edge class operator: slab exceeds 2^31 / 3 elements per component (use more z-slabs)");
-    const size_t n_alloc = 3 * c->nloc + (size_t)c->plane + 64;   // same slack as fdtd_set_operator_classes
+    const size_t n_alloc = 3 * c->nloc + 64;   // same slack as fdtd_set_operator_classes
     if (!c->ecls) HIPCK(c, hipMalloc(&c->ecls, n_alloc));
     HIPCK(c, hipMemsetAsync(c->ecls, 0, n_alloc, c->stream));
     DevBuf<unsigned long long> d_tri;
@@ -367,7 +367,6 @@ int fdtd_build_operator(fdtd_ctx* c, const double* dx, const double* dy, const d
     c->op_nclasses = 0;
   }
   HIPCK(c, hipGetLastError());
-  c->fused_ready = false;
   return FDTD_OK;
 }
 

@@ -66,13 +66,13 @@ enum { FDTD_KIND_V = 0, FDTD_KIND_I = 1 };           /* edge voltages (E) / face
 enum { FDTD_PHASE_E = 0, FDTD_PHASE_H = 1 };
 enum { FDTD_HALO_H_UP = 0, FDTD_HALO_E_DOWN = 1 };   /* Ix,Iy top plane -> rank+1 ; Vx,Vy bottom plane -> rank-1 */
 
-/* Kernel selection (fdtd_desc.flags) — all variants compute bit-identical results. */
+/* Kernel selection (fdtd_desc.flags). */
 enum {
-  FDTD_FLAG_KERNEL_AUTO   = 0,   /* the faster variant for the scene (currently the two-pass kernels) */
-  FDTD_FLAG_KERNEL_DIRECT = 1,   /* two-pass leapfrog: one E launch + one H launch per step */
-  FDTD_FLAG_KERNEL_FUSED  = 2,   /* one-pass leapfrog, neighbours recomputed per thread (ping-pong buffers); error if not eligible */
-  FDTD_FLAG_KERNEL_TILE   = 3,   /* one-pass leapfrog, neighbours shared through an LDS tile (overlapped 16x8x8 tiling) */
-  FDTD_FLAG_KERNEL_MARCH  = 4,   /* one-pass leapfrog, 16x16 xy tiles marching through z with an LDS-shared E plane */
+  FDTD_FLAG_KERNEL_AUTO   = 0,   /* the two-pass kernels: one E launch + one H launch per step */
+  FDTD_FLAG_KERNEL_DIRECT = 1,   /* the same, named explicitly */
+  /* 2..4 were the three one-pass (fused E+H) variants of ABI v1 — per-thread recompute, overlapped LDS tiles, z-marching
+     tiles.  All were bit-exact and all measured slower than the two passes on every workload (profiles/r01); removed in
+     v2, selecting them is FDTD_E_UNSUPPORTED. */
   FDTD_FLAG_KERNEL_MASK   = 0xF,
   FDTD_FLAG_NO_GRAPH      = 0x10, /* reserved */
   FDTD_FLAG_OVERLAP_ON    = 0x20, /* multi-slab: split sweeps into interior + halo-dependent plane (the default) */
@@ -97,14 +97,14 @@ typedef struct fdtd_desc {
 
 typedef struct fdtd_profile {
   double ms_total;        /* stream time for the profiled steps, HIP events */
-  double ms_update_e;     /* average duration of one E half-step main kernel launch (net of ms_event_overhead) */
-  double ms_update_h;     /* average duration of one H half-step main kernel launch (net of ms_event_overhead) */
+  double ms_update_e;     /* average begin-to-end duration of one E half-step main kernel launch */
+  double ms_update_h;     /* average begin-to-end duration of one H half-step main kernel launch */
   int32_t launches_e;     /* launches averaged */
   int32_t launches_h;
   int32_t steps;
-  int32_t fused;          /* 1: one fused launch per step (ms_update_e = that launch, ms_update_h = 0) */
-  double ms_event_overhead; /* interval of an event pair with nothing between, same stream, measured in the same
-                               call and already subtracted from ms_update_e/h (the event packets' own time) */
+  int32_t fused;          /* always 0 since ABI v2 (field kept for layout compatibility) */
+  double ms_event_overhead; /* always 0 since ABI v2: the durations are the dispatches' own begin / end timestamps
+                               (start / stop events carried by each launch), nothing is subtracted */
 } fdtd_profile;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -200,7 +200,7 @@ int fdtd_rec_transform(fdtd_ctx* ctx, int id, int nfreq, const double* tw, doubl
 /* Run nsteps full leapfrog steps (halo exchange inside when world > 1 and a communicator is set).
  * Blocks until the device is idle. */
 int fdtd_run(fdtd_ctx* ctx, int nsteps);
-/* Same, but brackets the loop and every main-kernel launch with HIP events on the engine's stream. */
+/* Same (1..4096 steps), with start / stop events on every main-kernel launch: their begin / end timestamps. */
 int fdtd_run_profiled(fdtd_ctx* ctx, int nsteps, fdtd_profile* out);
 int fdtd_get_step(fdtd_ctx* ctx, int64_t* step);
 /* sums[0] = sum V^2, sums[1] = sum I^2 over the owned planes. */

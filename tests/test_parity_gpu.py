@@ -31,30 +31,36 @@ def _run_both(sim_factory, hip_lib, oracle_lib, steps, seed=None, flags=0):
     return out
 
 
-def _kflags(kernel):
-    capi = pkg("_capi")
-    return {"direct": capi.FLAG_KERNEL_DIRECT, "fused": capi.FLAG_KERNEL_FUSED, "tile": capi.FLAG_KERNEL_TILE,
-            "march": capi.FLAG_KERNEL_MARCH}[kernel]
-
-
-@pytest.mark.parametrize("kernel", ["fused", "tile", "march", "direct"])
 @pytest.mark.parametrize("use_classes", [True, False])
 @pytest.mark.parametrize("shape", [(64, 60, 36), (53, 47, 31)])
-def test_fields_bitexact_cpml(hip_lib, oracle_lib, shape, use_classes, kernel):
-    """kernel = fused: one-pass E+H sweep with ping-pong buffers (class operators only; the raw operator
-    falls back to two passes under AUTO); direct: two-pass leapfrog."""
-    capi = pkg("_capi")
-    if kernel != "direct" and not use_classes:
-        pytest.skip("the one-pass kernels need the class-compressed operator")
-    flags = _kflags(kernel)
+def test_fields_bitexact_cpml(hip_lib, oracle_lib, shape, use_classes):
+    """Class-compressed and raw operator, nx a multiple of 4 and not, CPML on all faces."""
     (sh, eh), (so, eo) = _run_both(lambda: patch_sim(*shape, boundary="CPML", cpml_cells=8, nr_ts=300,
-                                                     use_classes=use_classes), hip_lib, oracle_lib, 300, seed=1, flags=flags)
+                                                     use_classes=use_classes), hip_lib, oracle_lib, 300, seed=1)
     assert eh.backend.startswith("hip") and eo.backend.startswith("oracle")
     fh, fo = eh.fields(), eo.fields()
     assert np.isfinite(fo).all() and np.abs(fo).max() > 0
     assert same_values(fh, fo), f"rel L2 {rel_l2(fh, fo):.3e}"
     nz = fo != 0
     assert np.array_equal(fh[nz].view(np.uint32), fo[nz].view(np.uint32))
+
+
+@pytest.mark.parametrize("cells", [3, 12])
+def test_fields_bitexact_cpml_layer_thickness(hip_lib, oracle_lib, cells):
+    """CPML layers thinner than, and a multiple of, the 4-cell groups the kernels work in (the x ranges are aligned
+    internally: cells drawn into the aligned range carry identity coefficients)."""
+    (sh, eh), (so, eo) = _run_both(lambda: patch_sim(50, 46, 33, boundary="CPML", cpml_cells=cells, nr_ts=200), hip_lib, oracle_lib, 200, seed=4)
+    fh, fo = eh.fields(), eo.fields()
+    assert np.abs(fo).max() > 0 and same_values(fh, fo), f"rel L2 {rel_l2(fh, fo):.3e}"
+
+
+def test_fields_bitexact_cpml_thick_x_layers(hip_lib, oracle_lib):
+    """x layers of 66 cells on both sides: more aligned x-layer cells than the kernels' LDS coefficient table holds
+    (XC_MAX = 128), so the kernels read the x coefficients from global memory; PEC on the other faces."""
+    bc = ["CPML", "CPML", "PEC", "PEC", "PEC", "PEC"]
+    (sh, eh), (so, eo) = _run_both(lambda: patch_sim(200, 30, 26, boundary=bc, cpml_cells=66, nr_ts=150, nf2ff=False), hip_lib, oracle_lib, 150, seed=6)
+    fh, fo = eh.fields(), eo.fields()
+    assert np.abs(fo).max() > 0 and same_values(fh, fo), f"rel L2 {rel_l2(fh, fo):.3e}"
 
 
 def test_fields_bitexact_mur(hip_lib, oracle_lib):
@@ -88,31 +94,27 @@ def test_port_probes_dft_energy(hip_lib, oracle_lib):
     assert abs(evh - evo) <= 1e-10 * evo and abs(eih - eio) <= 1e-10 * eio
 
 
-def test_fused_flag_rejects_ineligible_scene(hip_lib):
+def test_removed_kernel_selection_is_rejected(hip_lib):
+    """Flags 2..4 selected the one-pass variants of ABI v1; they were removed: a clean FDTD_E_UNSUPPORTED."""
     capi = pkg("_capi")
-    s = patch_sim(40, 40, 30, boundary="MUR", nr_ts=20, nf2ff=False)
-    e = s.build(hip_lib, flags=capi.FLAG_KERNEL_FUSED)
-    with pytest.raises(capi.FdtdError, match="fused kernel needs"):
+    s = patch_sim(40, 40, 30, nr_ts=20, nf2ff=False)
+    e = s.build(hip_lib, flags=2)
+    with pytest.raises(capi.FdtdError, match="removed"):
         e.run(2)
 
 
-@pytest.mark.parametrize("kernel", ["fused", "tile", "march"])
-def test_fused_no_pml_and_odd_sizes(hip_lib, oracle_lib, kernel):
-    """PEC box (no CPML template path), nx not a multiple of 4, sources + probes, one-pass kernels vs oracle."""
-    capi = pkg("_capi")
-    (sh, eh), (so, eo) = _run_both(lambda: patch_sim(45, 43, 29, boundary="PEC", nr_ts=400, nf2ff=False), hip_lib, oracle_lib, 400,
-                                   flags=_kflags(kernel))
+def test_no_pml_and_odd_sizes(hip_lib, oracle_lib):
+    """PEC box (the template path without CPML), nx not a multiple of 4, sources + probes vs the oracle."""
+    (sh, eh), (so, eo) = _run_both(lambda: patch_sim(45, 43, 29, boundary="PEC", nr_ts=400, nf2ff=False), hip_lib, oracle_lib, 400)
     assert same_values(eh.fields(), eo.fields()) and np.abs(eo.fields()).max() > 0
     assert rel_l2(sh.port_series()[0][0], so.port_series()[0][0]) < 1e-12
 
 
-@pytest.mark.parametrize("kernel", ["fused", "tile", "march", "direct"])
-def test_chunked_runs_and_fused_probes(hip_lib, oracle_lib, kernel):
+def test_chunked_runs_and_fused_probes(hip_lib, oracle_lib):
     """fdtd_run in uneven chunks (probe flush at every call end, sources injected inside the main kernels)
     must give the same series as the oracle's plain loop."""
-    capi = pkg("_capi")
     sh, so = patch_sim(48, 44, 32, nr_ts=700), patch_sim(48, 44, 32, nr_ts=700)
-    eh = sh.build(hip_lib, flags=_kflags(kernel))
+    eh = sh.build(hip_lib)
     eo = so.build(oracle_lib)
     for n in (1, 2, 97, 250, 349, 1):
         eh.run(n)

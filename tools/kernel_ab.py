@@ -23,7 +23,18 @@ def main():
     wl = importlib.import_module(PKG + ".workloads")
     sc = importlib.import_module(PKG + ".scene")
     simm = importlib.import_module(PKG + ".simulation")
-    lib = capi.load_hip_library(os.environ.get("FDTD_HIP_LIB_DIR") or None)
+    libdir = os.environ.get("FDTD_HIP_LIB_DIR") or None
+    if libdir:   # an older build (e.g. the previous round's kernels) may lack newer entry points this tool never calls
+        import ctypes
+        raw = ctypes.CDLL(capi.hip_library_path(libdir))
+        for name in capi.ABI_SYMBOLS:
+            try:
+                getattr(raw, name)
+            except AttributeError:
+                setattr(raw, name, raw["fdtd_version"])
+        lib = capi.bind(raw)
+    else:
+        lib = capi.load_hip_library()
     for name in names:
         w = wl.baseline_workload(name)
         vox = sc.voxelize(w.scene, w.grid)
