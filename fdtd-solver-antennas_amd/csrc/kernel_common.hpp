@@ -78,6 +78,14 @@ __device__ __forceinline__ float4 ld4_sys(const float* q) {
 // registers AFTER issue, and a VALU write to them in the next wait states corrupts what the later lanes store (hipcc pads
 // its own stores; it cannot see into an asm statement).  Found by the data-path self-test of the mailbox transport: the
 // last 64 bytes of every 256 of one plane arrived with a compiler temporary (0 / 1) in their first word.
+// two of them with ONE wait (the halo-dependent plane reads two components): both round trips overlap
+__device__ __forceinline__ void ld4x2_sys(const float* qa, const float* qb, float4& a, float4& b) {
+  v4f_sys ra, rb;
+  asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(ra), "=&v"(rb) : "v"(qa), "v"(qb) : "memory");
+  a = make_float4(ra.x, ra.y, ra.z, ra.w);
+  b = make_float4(rb.x, rb.y, rb.z, rb.w);
+}
 __device__ __forceinline__ void st4_sys(float* q, const float4& v) {
   const v4f_sys t = {v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(q), "v"(t) : "memory");

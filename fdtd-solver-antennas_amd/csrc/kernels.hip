@@ -99,8 +99,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, (COEF == 0 && P2P) ? FDTD_E_MINBLOCKS -
   if (dep_in) {   // H halo of step-1 (flag value = steps delivered); parity of the step that produced it
     p2p_wait(p.fl_in + 1, (unsigned)step, p.p2p_err, p.p2p_limit);
     const float* mb = p.mb_in_H + (size_t)((step + 1) & 1) * 2 * p.plane + (j * p.P + i0);
-    ix_km = ld4_sys(mb);
-    iy_km = ld4_sys(mb + p.plane);
+    ld4x2_sys(mb, mb + p.plane, ix_km, iy_km);
   }
 
   // component x: d1 along y (of Iz), d2 along z (of Iy); y: d1 along z (Ix), d2 along x (Iz);
@@ -241,8 +240,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, RAW ? FDTD_H_MINBLOCKS - 1 : FDTD_H_MIN
   if (dep_in) {   // E halo of this step
     p2p_wait(p.fl_in + 0, (unsigned)step + 1u, p.p2p_err, p.p2p_limit);
     const float* mb = p.mb_in_E + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
-    vx_kp = ld4_sys(mb);
-    vy_kp = ld4_sys(mb + p.plane);
+    ld4x2_sys(mb, mb + p.plane, vx_kp, vy_kp);
   }
 
   float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);
