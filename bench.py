@@ -86,7 +86,7 @@ def main():
     vox = sc.voxelize(w.scene, w.grid)
     nts_total = (args.steps + args.warmup) * args.ts_per_step * 2 + 8
     sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=args.cpml_cells,
-                          nr_ts=nts_total, nf2ff_freqs=[w.f0], use_classes=not args.raw_operator)
+                          nr_ts=nts_total, nf2ff_freqs=[w.f0], nf2ff_mode="auto", use_classes=not args.raw_operator)
     eng = sim.build(hip, rank=rank, world=world, device=local_rank)
     comm = None
     if world > 1:
@@ -176,7 +176,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w.grid.shape[0]}x{w.grid.shape[1]}x{w.grid.shape[2]} "
                                    f"{SCENES.get(args.workload, 'patch')}, CPML-{args.cpml_cells}, "
-                                   f"{len(vox.ports)} lumped port(s), NF2FF DFT surfaces",
+                                   f"{len(vox.ports)} lumped port(s), NF2FF surfaces ({sim.nf2ff_mode})",
                        "cells": ncells, "timesteps_per_step": tps, "operator": operator_form,
                        "parallelism": f"z-slab x{world}, halo transport {comm.transport_used}" if world > 1 else "single GPU",
                        "fields_finite": finite, "port_u_l2": port_u_l2, "timesteps_total": steps_total},

@@ -303,8 +303,8 @@ __device__ __forceinline__ int psi_off_y(const DevParams& p, const int k, const 
   const int sy = pml_slot(p, 1, j);
   return sy < 0 ? -1 : (k * p.nslot[1] + sy) * p.P + i0;
 }
-// (the y-directed pair stays a direct load in the kernels: staging it as well — tried, slots 2,3 where no z pair sits —
-// pushed both kernels over their register budget; the y layers are 5-7 % of the blocks)
+// Slots 2,3 take the z-directed pair in the z-layer planes (block-uniform: a block lies in one plane) and the y-directed
+// pair elsewhere; where both layers meet (edges, corners) the y pair is loaded directly, after the differences, as before.
 __device__ __forceinline__ void psi_stage_issue(const DevParams& p, float* const (&psi)[3][2], const unsigned stage, const bool valid,
                                                 const int k, const int j, const int i0) {
   if (!valid) return;
@@ -313,29 +313,57 @@ __device__ __forceinline__ void psi_stage_issue(const DevParams& p, float* const
     glds16o(psi[1][1], (unsigned)ox, stage);
     glds16o(psi[2][0], (unsigned)ox, stage + 1024u);
   }
-  const int oz = psi_off_z(p, k, j, i0);
+  const int oz = psi_off_z(p, k, j, i0);   // >= 0 for the whole block or for none of it (a block lies in one plane)
   if (oz >= 0) {
     glds16o(psi[0][1], (unsigned)oz, stage + 2048u);
     glds16o(psi[1][0], (unsigned)oz, stage + 3072u);
+  } else {                                  // outside the z layers the same two slots take the y-directed pair
+    const int oy = psi_off_y(p, k, j, i0);
+    if (oy >= 0) {
+      glds16o(psi[0][0], (unsigned)oy, stage + 2048u);
+      glds16o(psi[2][1], (unsigned)oy, stage + 3072u);
+    }
   }
 }
 // ... and use them: z pair on (dzA, dzB) = the two differences taken along z, x pair on (dxA, dxB) = along x.
 __device__ __forceinline__ void psi_stage_apply(const DevParams& p, float* const (&psi)[3][2], const int eh, const float4* s_psi, const float* s_xc,
                                                 const bool xc_lds, const int k, const int j, const int i0,
-                                                float4& dzA, float4& dzB, float4& dxA, float4& dxB) {
+                                                float4& dzA, float4& dzB, float4& dxA, float4& dxB, float4& dyA, float4& dyB) {
   const int ox = psi_off_x(p, k, j, i0), oz = psi_off_z(p, k, j, i0);   // recomputed, not carried: registers
   const float4* mine = s_psi + (threadIdx.x >> 6) * (PSI_SLOTS * 64) + (threadIdx.x & 63u);
   // one psi array at a time, fenced: the scheduler would otherwise keep all four staged values and the coefficient vectors
   // live at once, and this kernel has no registers to spare
-  if (oz >= 0) {
-    const float b = p.cp[2][eh][0][k], c = p.cp[2][eh][1][k], ik = p.cp[2][eh][2][k];
-    float4 ps = mine[2 * 64];
-    cpml_row4_reg(dzA, ps, b, c, ik);
-    sto4(psi[0][1], (unsigned)oz, ps);
+  if (oz >= 0) {   // z-layer plane (uniform over the block): z pair from the stage, y pair (edges) by direct loads
+    {
+      const float b = p.cp[2][eh][0][k], c = p.cp[2][eh][1][k], ik = p.cp[2][eh][2][k];
+      float4 ps = mine[2 * 64];
+      cpml_row4_reg(dzA, ps, b, c, ik);
+      sto4(psi[0][1], (unsigned)oz, ps);
+      __builtin_amdgcn_sched_barrier(0);
+      ps = mine[3 * 64];
+      cpml_row4_reg(dzB, ps, b, c, ik);
+      sto4(psi[1][0], (unsigned)oz, ps);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    ps = mine[3 * 64];
-    cpml_row4_reg(dzB, ps, b, c, ik);
-    sto4(psi[1][0], (unsigned)oz, ps);
+    const int oy = psi_off_y(p, k, j, i0);
+    if (oy >= 0) {
+      const float b = p.cp[1][eh][0][j], c = p.cp[1][eh][1][j], ik = p.cp[1][eh][2][j];
+      cpml_row4(dyA, psi[0][0], (unsigned)oy, b, c, ik);
+      __builtin_amdgcn_sched_barrier(0);
+      cpml_row4(dyB, psi[2][1], (unsigned)oy, b, c, ik);
+    }
+  } else {         // elsewhere the stage holds the y pair
+    const int oy = psi_off_y(p, k, j, i0);
+    if (oy >= 0) {
+      const float b = p.cp[1][eh][0][j], c = p.cp[1][eh][1][j], ik = p.cp[1][eh][2][j];
+      float4 ps = mine[2 * 64];
+      cpml_row4_reg(dyA, ps, b, c, ik);
+      sto4(psi[0][0], (unsigned)oy, ps);
+      __builtin_amdgcn_sched_barrier(0);
+      ps = mine[3 * 64];
+      cpml_row4_reg(dyB, ps, b, c, ik);
+      sto4(psi[2][1], (unsigned)oy, ps);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   if (ox >= 0) {

@@ -35,7 +35,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // COEF: 0 raw arrays, 1 class byte per edge, 2 one packed class byte per cell
 template <int COEF, bool PML, bool FUSE, bool P2P>
-__global__ __launch_bounds__(FDTD_BLOCK, (COEF == 0 && P2P) ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const FastDiv fd_ps,
+__global__ __launch_bounds__(FDTD_BLOCK, (PML || (COEF == 0 && P2P)) ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const FastDiv fd_ps,
                                                                             const long long step, const int extra, const unsigned nb_main) {
   extern __shared__ float2 s_lut[];   // coefficient table, lut_n entries (dynamic: scenes use a few dozen of the up to 768)
   // CPML psi staging (LDS-DMA, 16 KiB); the probe block borrows it for its reduction
@@ -121,16 +121,16 @@ __global__ __launch_bounds__(FDTD_BLOCK, (COEF == 0 && P2P) ? FDTD_E_MINBLOCKS -
   if (!valid) return;
 
   if (PML) {
-    const int sy = pml_slot(p, 1, j);
-    if (sy >= 0) {
-      const float b = p.cp[1][0][0][j], c = p.cp[1][0][1][j], ik = p.cp[1][0][2][j];
-      const int o = (k * p.nslot[1] + sy) * p.P + i0;
-      cpml_row4(dx1, p.psiE[0][0], (unsigned)o, b, c, ik);
-      cpml_row4(dz2, p.psiE[2][1], (unsigned)o, b, c, ik);
-    }
     if (FDTD_PSI_STAGE) {
-      psi_stage_apply(p, p.psiE, 0, s_psi, s_xc, xc_lds, k, j, i0, dx2, dy1, dy2, dz1);
+      psi_stage_apply(p, p.psiE, 0, s_psi, s_xc, xc_lds, k, j, i0, dx2, dy1, dy2, dz1, dx1, dz2);
     } else {
+      const int sy = pml_slot(p, 1, j);
+      if (sy >= 0) {
+        const float b = p.cp[1][0][0][j], c = p.cp[1][0][1][j], ik = p.cp[1][0][2][j];
+        const int o = (k * p.nslot[1] + sy) * p.P + i0;
+        cpml_row4(dx1, p.psiE[0][0], (unsigned)o, b, c, ik);
+        cpml_row4(dz2, p.psiE[2][1], (unsigned)o, b, c, ik);
+      }
       const int sz = pml_slot(p, 2, k);
       if (sz >= 0) {
         const float b = p.cp[2][0][0][k], c = p.cp[2][0][1][k], ik = p.cp[2][0][2][k];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, (COEF == 0 && P2P) ? FDTD_E_MINBLOCKS -
 // K2: H half-step
 // ------------------------------------------------------------------------------------------------
 template <bool RAW, bool PML, bool P2P>
-__global__ __launch_bounds__(FDTD_BLOCK, RAW ? FDTD_H_MINBLOCKS - 1 : FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const FastDiv fd_ps,
+__global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const FastDiv fd_ps,
                                                                             const long long step, const int extra, const unsigned nb_main) {
   // CPML psi staging (LDS-DMA, 16 KiB); the probe block borrows it for its reduction
   __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : FDTD_BLOCK / 2];
@@ -256,16 +256,16 @@ __global__ __launch_bounds__(FDTD_BLOCK, RAW ? FDTD_H_MINBLOCKS - 1 : FDTD_H_MIN
   }
 
   if (PML) {
-    const int sy = pml_slot(p, 1, j);
-    if (sy >= 0) {
-      const float b = p.cp[1][1][0][j], c = p.cp[1][1][1][j], ik = p.cp[1][1][2][j];
-      const int o = (k * p.nslot[1] + sy) * p.P + i0;
-      cpml_row4(dx1, p.psiH[0][0], (unsigned)o, b, c, ik);
-      cpml_row4(dz2, p.psiH[2][1], (unsigned)o, b, c, ik);
-    }
     if (FDTD_PSI_STAGE) {
-      psi_stage_apply(p, p.psiH, 1, s_psi, s_xc, xc_lds, k, j, i0, dx2, dy1, dy2, dz1);
+      psi_stage_apply(p, p.psiH, 1, s_psi, s_xc, xc_lds, k, j, i0, dx2, dy1, dy2, dz1, dx1, dz2);
     } else {
+      const int sy = pml_slot(p, 1, j);
+      if (sy >= 0) {
+        const float b = p.cp[1][1][0][j], c = p.cp[1][1][1][j], ik = p.cp[1][1][2][j];
+        const int o = (k * p.nslot[1] + sy) * p.P + i0;
+        cpml_row4(dx1, p.psiH[0][0], (unsigned)o, b, c, ik);
+        cpml_row4(dz2, p.psiH[2][1], (unsigned)o, b, c, ik);
+      }
       const int sz = pml_slot(p, 2, k);
       if (sz >= 0) {
         const float b = p.cp[2][1][0][k], c = p.cp[2][1][1][k], ik = p.cp[2][1][2][k];
