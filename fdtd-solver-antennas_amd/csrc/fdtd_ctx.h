@@ -40,6 +40,16 @@ inline FastDiv make_fastdiv(unsigned d) {
   return f;
 }
 
+// First-order Mur faces as the kernels see them (k_mur, and the "pre" pass riding in the update_H launch)
+struct MurDevFace {
+  int on, a, b, in;      // axis, local boundary index, inner index
+  int ua, va, du, dv;    // in-face axes (u fast), extents
+  float coeff;
+  float* st[2];
+  int comp[2];
+};
+struct MurDev { MurDevFace f[6]; int bnd[6]; /* local boundary index per face, for the priority rule */ };
+
 struct DevParams {
   int nx, ny, nk, P, P4;
   int plane;  // ny * P (floats)
@@ -83,6 +93,10 @@ struct DevParams {
   int nsrc; const int* src_off; const int8_t* src_comp; const float* src_amp; const int* src_delay;
   const float* sig; int nsig;
   const struct DevProbe* probes; int nprobe; int max_steps;
+  // Mur "pre" pass of the NEXT step as extra blocks of the update_H launch (it only reads V, which update_H does not write)
+  const MurDev* mur;         // device copy of the face table (null without Mur faces)
+  int mur_nbx;               // blocks per (face, component) row
+  int mur_nb;                // Mur blocks in THIS launch (0: none) — set by the launcher
 };
 
 struct DevProbe { int kind, n; const int* off; const int8_t* comp; const float* w; double* series; };
@@ -117,6 +131,8 @@ struct fdtd_ctx {
   // mur
   MurFace mur[6] = {};
   bool any_mur = false;
+  MurDev h_mur{}; MurDev* d_mur = nullptr;   // face table (built by fdtd_set_mur), host and device copy
+  int64_t mur_pre_step = -1;                 // step whose Mur pre pass has already run (inside the previous update_H launch)
   // excitation
   float* sig = nullptr; int nsig = 0;
   int nsrc = 0; int* src_off = nullptr; int8_t* src_comp = nullptr; float* src_amp = nullptr; int* src_delay = nullptr;
@@ -157,7 +173,8 @@ int fdtd_fail(fdtd_ctx* c, int code, const char* fmt, ...);
 // (update_E: I-probes of step-1, update_H: V-probes of step) so a step is exactly two launches.
 int upload_metric_tables(fdtd_ctx* c, const float* emet, const float* hmet);
 void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool fused, bool probe_block, hipStream_t s);
-void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s);
+void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s, bool mur_pre = false);
+int build_mur_table(fdtd_ctx* c);   // after fdtd_set_mur: face table -> device
 void launch_mur(fdtd_ctx* c, int mode, hipStream_t s);
 void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_t s);   // stand-alone sources + probes
 void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);   // running DFT or time-domain recording of the boxes

@@ -196,6 +196,26 @@ __global__ __launch_bounds__(FDTD_BLOCK, (PML || (COEF == 0 && P2P)) ? FDTD_E_MI
   }
 }
 
+// Mur "pre" pass (mode 0 of k_mur) of one block: S = V_inner - coeff * V_boundary on the values BEFORE the next E update.
+// e = block index among the Mur blocks of the launch: (face * 2 + tangential component) * mur_nbx + block within the face.
+__device__ __forceinline__ void mur_pre_block(const DevParams& p, const unsigned e) {
+  const MurDev& m = *p.mur;
+  const unsigned row = e / (unsigned)p.mur_nbx, bx = e - row * (unsigned)p.mur_nbx;
+  const int fi = (int)(row >> 1), t = (int)(row & 1u);
+  const MurDevFace& f = m.f[fi];
+  if (!f.on) return;
+  const int s = (int)(bx * FDTD_BLOCK + threadIdx.x);
+  if (s >= f.du * f.dv) return;
+  const int iv = s / f.du, iu = s - iv * f.du;
+  const int stride[3] = {1, p.P, p.plane};
+  int pos[3];
+  pos[f.a] = f.b; pos[f.ua] = iu; pos[f.va] = iv;
+  const float* V = p.V[f.comp[t]];
+  const int ob = pos[0] + pos[1] * p.P + pos[2] * p.plane;
+  const int oi = ob + (f.in - f.b) * stride[f.a];
+  f.st[t][s] = __builtin_fmaf(-f.coeff, V[ob], V[oi]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: H half-step
 // ------------------------------------------------------------------------------------------------
@@ -206,8 +226,10 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
   __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : FDTD_BLOCK / 2];
   __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
   double* const s_red = reinterpret_cast<double*>(s_psi);
-  if (extra && blockIdx.x == gridDim.x - 1) {   // probe block: V-probes of this step (V is final, H not read)
-    probe_block(p, FDTD_KIND_V, step, s_red);
+  if (extra && blockIdx.x >= gridDim.x - (unsigned)extra) {   // the extra blocks at the end of the grid:
+    const unsigned e = blockIdx.x - (gridDim.x - (unsigned)extra);
+    if (e < (unsigned)p.mur_nb) mur_pre_block(p, e);          // Mur pre pass of the next step (V is final, H not read)
+    else probe_block(p, FDTD_KIND_V, step, s_red);            // last one: V-probes of this step
     return;
   }
   int strip, kk, pb, j = 0, i0 = 0, k;
@@ -313,15 +335,6 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
 // ------------------------------------------------------------------------------------------------
 // K4: Mur.  One thread per face point and tangential component; blockIdx.y = face*2 + t.
 // ------------------------------------------------------------------------------------------------
-struct MurDevFace {
-  int on, a, b, in;      // axis, local boundary index, inner index
-  int ua, va, du, dv;    // in-face axes (u fast), extents
-  float coeff;
-  float* st[2];
-  int comp[2];
-};
-struct MurDev { MurDevFace f[6]; int bnd[6]; /* local boundary index per face, for the priority rule */ };
-
 __global__ __launch_bounds__(FDTD_BLOCK) void k_mur(const DevParams p, const MurDev m, const int mode) {
   const int fi = blockIdx.y >> 1, t = blockIdx.y & 1;
   const MurDevFace& f = m.f[fi];
@@ -550,10 +563,13 @@ static void launch_H2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long st
   launch_main(c, k_update_H<RAW, PML, false>, grid, pad, s, c->p, k_begin, fd_ps, step, extra, 0u);
 }
 
-void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s) {
+void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s, bool mur_pre) {
   const int nkr = k_end - k_begin;
   if (nkr <= 0) return;
-  const int extra = probe_block ? 1 : 0;
+  // extra blocks behind the main ones: [Mur pre pass of the next step (12 rows of mur_nbx blocks)] [probe block]; the Mur
+  // blocks only ride along when the probe block does (the kernel tells them apart by their distance from the end)
+  c->p.mur_nb = (mur_pre && probe_block && c->any_mur && c->d_mur) ? 12 * c->p.mur_nbx : 0;
+  const int extra = (probe_block ? 1 : 0) + c->p.mur_nb;
   const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs + extra));
   if (c->raw_op) {
     if (c->have_cpml) launch_H2<true, true>(c, grid, k_begin, nkr, step, extra, s);
@@ -564,9 +580,10 @@ void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool p
   }
 }
 
-void launch_mur(fdtd_ctx* c, int mode, hipStream_t s) {
-  if (!c->any_mur) return;
-  MurDev m{};
+// face table of the context's Mur faces -> host copy + device copy (DevParams::mur)
+int build_mur_table(fdtd_ctx* c) {
+  MurDev& m = c->h_mur;
+  m = MurDev{};
   const int dim[3] = {c->p.nx, c->p.ny, c->p.nk};
   int maxpts = 1;
   for (int f = 0; f < 6; ++f) {
@@ -587,8 +604,20 @@ void launch_mur(fdtd_ctx* c, int mode, hipStream_t s) {
     d.comp[0] = pa; d.comp[1] = qa;
     if (d.on && d.du * d.dv > maxpts) maxpts = d.du * d.dv;
   }
-  const dim3 grid((unsigned)((maxpts + FDTD_BLOCK - 1) / FDTD_BLOCK), 12), block(FDTD_BLOCK);
-  hipLaunchKernelGGL(k_mur, grid, block, 0, s, c->p, m, mode);
+  c->p.mur_nbx = (maxpts + FDTD_BLOCK - 1) / FDTD_BLOCK;
+  c->p.mur = nullptr; c->p.mur_nb = 0;
+  c->mur_pre_step = -1;
+  if (!c->any_mur) return FDTD_OK;
+  if (!c->d_mur) HIPCK(c, hipMalloc(&c->d_mur, sizeof(MurDev)));
+  HIPCK(c, hipMemcpy(c->d_mur, &m, sizeof(MurDev), hipMemcpyHostToDevice));
+  c->p.mur = c->d_mur;
+  return FDTD_OK;
+}
+
+void launch_mur(fdtd_ctx* c, int mode, hipStream_t s) {
+  if (!c->any_mur) return;
+  const dim3 grid((unsigned)c->p.mur_nbx, 12), block(FDTD_BLOCK);
+  hipLaunchKernelGGL(k_mur, grid, block, 0, s, c->p, c->h_mur, mode);
 }
 
 void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s) {
