@@ -178,13 +178,9 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   p.nt = ((size_t)c->nloc * (6 * sizeof(float) + 1) > (size_t)200 << 20) ? 1 : 0;
   choose_tiling(c);
   p.sweep_rev = getenv("FDTD_NO_SWEEP_REV") ? 0 : 1;
-  if (const char* kc = getenv("FDTD_MARCH_KC")) {
-    const int v = atoi(kc);
-    if (v >= 1 && v <= 4096) c->march_kc = v;
-  }
   if (const char* v = getenv("FDTD_OCC_E")) c->occ_e = std::max(0, std::min(16, atoi(v)));
   if (const char* v = getenv("FDTD_OCC_H")) c->occ_h = std::max(0, std::min(16, atoi(v)));
-  p.src_rng = nullptr; p.src_ids = nullptr; p.src_rng4 = nullptr; p.src_ids4 = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
+  p.src_rng = nullptr; p.src_ids = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
   p.sig = c->sig; p.nsig = 0;
   p.probes = c->d_probe; p.nprobe = 0; p.max_steps = d->max_steps;
   *out = c;
@@ -209,8 +205,7 @@ void fdtd_destroy(fdtd_ctx* c) {
   }
   for (int b = 0; b < c->nbox; ++b) { hipFree(c->box[b].acc); hipFree(c->box[b].rec); }
   hipFree(c->d_probe); hipFree(c->d_box); hipFree(c->tw_v); hipFree(c->tw_i);
-  hipFree(c->d_energy); hipFree(c->src_rng); hipFree(c->src_ids); hipFree(c->src_rng4); hipFree(c->src_ids4);
-  for (int n = 0; n < 6; ++n) hipFree(c->fieldbase2[n]);
+  hipFree(c->d_energy); hipFree(c->src_rng); hipFree(c->src_ids);
   if (c->peer_lo && c->peer_lo_ipc) hipIpcCloseMemHandle(c->peer_lo);
   if (c->peer_hi && c->peer_hi_ipc) hipIpcCloseMemHandle(c->peer_hi);
   hipFree(c->mbox);
@@ -455,7 +450,6 @@ int fdtd_add_source(fdtd_ctx* c, int n, const int64_t* idx, const int8_t* comp, 
   HIPCK(c, to_device(&c->src_delay, c->h_src_delay));
   HIPCK(c, build_source_lists(c, c->p.tys, c->p.nstrips, &c->src_rng, &c->src_ids));
   c->p.src_rng = c->src_rng; c->p.src_ids = c->src_ids;
-  c->march_ready = false;
   c->p.nsrc = c->nsrc; c->p.src_off = c->src_off; c->p.src_comp = c->src_comp; c->p.src_amp = c->src_amp;
   c->p.src_delay = c->src_delay;
   return FDTD_OK;
@@ -704,57 +698,6 @@ static bool sources_fusable(const fdtd_ctx* c) {
   return true;
 }
 
-// ---- one-pass kernel (march.hip): eligibility, second buffer set, per-tile-column source lists ----------------------------
-static bool march_mode(const fdtd_ctx* c) { return (c->d.flags & FDTD_FLAG_KERNEL_MASK) == FDTD_FLAG_KERNEL_MARCH; }
-
-static int ensure_march(fdtd_ctx* c) {
-  if (c->d.world != 1 || c->any_mur || !c->have_op || c->raw_op || !c->packed_op || c->have_cpml)
-    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "one-pass kernel: needs a single slab, the packed class operator, no Mur faces and (for now) no CPML");
-  if (c->march_ready) return FDTD_OK;
-  const size_t fbytes = (size_t)c->plane * (c->d.nk + 2) * sizeof(float);
-  for (int n = 0; n < 6; ++n)
-    if (!c->fieldbase2[n]) {
-      HIPCK(c, hipMalloc(&c->fieldbase2[n], fbytes));
-      HIPCK(c, hipMemset(c->fieldbase2[n], 0, fbytes));
-    }
-  // which of the two allocations is "current" is tracked by p.V / p.I; the partner is the other one
-  for (int n = 0; n < 3; ++n) {
-    float* a = c->fieldbase[n] + c->plane; float* b = c->fieldbase2[n] + c->plane;
-    c->p.Vn[n] = (c->p.V[n] == a) ? b : a;
-    a = c->fieldbase[3 + n] + c->plane; b = c->fieldbase2[3 + n] + c->plane;
-    c->p.In[n] = (c->p.I[n] == a) ? b : a;
-  }
-  int ntx, nty, ntz, kc;
-  march_counts(c, ntx, nty, ntz, kc);
-  std::vector<std::vector<int>> lists((size_t)ntx * nty * ntz);
-  std::vector<int> tl;
-  for (size_t e = 0; e < c->h_src_off.size(); ++e) {
-    const int off = c->h_src_off[e];
-    const int k = off / c->plane, j = (off - k * c->plane) / c->P, i = off - k * c->plane - j * c->P;
-    tl.clear();
-    march_tiles_of_cell(c, i / 4, j, k, tl);
-    for (int t : tl) lists[t].push_back((int)e);
-  }
-  std::vector<int2> rng(lists.size());
-  std::vector<int> ids;
-  int mx = 0;
-  for (size_t q = 0; q < lists.size(); ++q) {
-    rng[q].x = (int)ids.size();
-    ids.insert(ids.end(), lists[q].begin(), lists[q].end());
-    rng[q].y = (int)ids.size();
-    mx = std::max(mx, (int)lists[q].size());
-  }
-  if (mx > FDTD_BLOCK) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "one-pass kernel: %d source edges in one tile column (limit %d)", mx, FDTD_BLOCK);
-  hipFree(c->src_rng4); hipFree(c->src_ids4); c->src_rng4 = nullptr; c->src_ids4 = nullptr;
-  HIPCK(c, hipMalloc(&c->src_rng4, rng.size() * sizeof(int2)));
-  HIPCK(c, hipMemcpy(c->src_rng4, rng.data(), rng.size() * sizeof(int2), hipMemcpyHostToDevice));
-  HIPCK(c, hipMalloc(&c->src_ids4, std::max<size_t>(ids.size(), 1) * sizeof(int)));
-  if (!ids.empty()) HIPCK(c, hipMemcpy(c->src_ids4, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
-  c->p.src_rng4 = c->src_rng4; c->p.src_ids4 = c->src_ids4;
-  c->march_ready = true;
-  return FDTD_OK;
-}
-
 struct ProfEvents {
   std::vector<hipEvent_t> e0, e1, h0, h1;
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -834,37 +777,11 @@ static int phase_H(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
 }
 
 static int step_loop_p2p(fdtd_ctx* c, int nsteps, struct ProfEvents* pe);
-static int step_loop_march(fdtd_ctx* c, int nsteps, struct ProfEvents* pe);
 static int p2p_check(fdtd_ctx* c);
 
-// One launch per step: new V and I go to the partner buffers, then the roles swap.  The probe block of launch n samples
-// both probe kinds of step n-1; the last step is flushed by stand-alone launches.
-static int step_loop_march(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
-  int r = ensure_march(c);
-  if (r) return r;
-  hipStream_t s = c->stream;
-  for (int n = 0; n < nsteps; ++n) {
-    const long long step = c->step;
-    if (pe) HIPCK(c, hipEventRecord(pe->e0[n], s));
-    launch_step_march(c, step, true, s);
-    if (pe) { HIPCK(c, hipEventRecord(pe->e1[n], s)); HIPCK(c, hipEventRecord(pe->h0[n], s)); HIPCK(c, hipEventRecord(pe->h1[n], s)); }
-    for (int q = 0; q < 3; ++q) { std::swap(c->p.V[q], c->p.Vn[q]); std::swap(c->p.I[q], c->p.In[q]); }
-    launch_dft(c, FDTD_KIND_V, step, s);
-    launch_dft(c, FDTD_KIND_I, step, s);
-    c->step++;
-  }
-  if (nsteps > 0) {
-    launch_post(c, FDTD_KIND_V, c->step - 1, false, s);
-    launch_post(c, FDTD_KIND_I, c->step - 1, false, s);
-  }
-  HIPCK(c, hipGetLastError());
-  return FDTD_OK;
-}
-
 static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
-  if (march_mode(c)) return step_loop_march(c, nsteps, pe);
   if ((c->d.flags & FDTD_FLAG_KERNEL_MASK) > FDTD_FLAG_KERNEL_DIRECT)
-    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "kernel selection %u: the one-pass variants 2 and 3 of ABI v1 were removed (measured slower than the two-pass kernels on every workload)", c->d.flags & FDTD_FLAG_KERNEL_MASK);
+    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "kernel selection %u: the one-pass variants were removed (measured slower than the two-pass kernels on every workload)", c->d.flags & FDTD_FLAG_KERNEL_MASK);
   if (c->p.p2p) return step_loop_p2p(c, nsteps, pe);
   const bool multi = c->d.world > 1;
   if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_p2p_attach (mailbox transport), fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
@@ -971,8 +888,8 @@ int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
     (void)hipGetLastError();
     out->ms_event_overhead = 0.0;
     out->ms_update_e = se / nsteps;
-    out->ms_update_h = march_mode(c) ? 0.0 : sh / nsteps;
-    out->fused = march_mode(c) ? 1 : 0;
+    out->ms_update_h = sh / nsteps;
+    out->fused = 0;
     out->launches_e = out->launches_h = nsteps;
   }
   destroy_all();
@@ -1001,7 +918,6 @@ int fdtd_half_step(fdtd_ctx* c, int phase) {
   int r = check_ready(c);
   if (r) return r;
   if (c->p.p2p) return fdtd_fail(c, FDTD_E_STATE, "fdtd_half_step drives an external halo transport; detach the p2p transport first");
-  if (march_mode(c)) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "the one-pass kernel has no half-steps");
   HIPCK(c, hipSetDevice(c->d.device));
   hipStream_t s = c->stream;
   c->mur_pre_step = -1;

@@ -56,8 +56,6 @@ struct DevParams {
   int nloc;   // nk * plane
   float* V[3];               // current fields (local plane 0; ghost planes at -plane and +nk*plane)
   float* I[3];
-  float* Vn[3];              // one-pass kernel (march.hip): next-step buffers (ping-pong), else null
-  float* In[3];
   // operator: raw arrays [3][nk*plane] or class bytes + LUT + 1-D metric tables
   const float* vv; const float* vi; const float* ii; const float* iv;
   const uint8_t* ecls;       // class mode: [3][nloc] one byte per edge; packed mode: [nloc] one byte per cell
@@ -90,8 +88,6 @@ struct DevParams {
   unsigned long long p2p_limit;   // wall-clock ticks a halo wait may last (10 s)
   int nt;                    // 1: non-temporal stores for the field outputs (working set beyond the Infinity Cache)
   // fused soft sources (update_E) and probes (extra block of update_E / update_H)
-  const int2* src_rng4;      // one-pass kernel: sources inside tile column id (xy footprint incl. feeders, planes kb..ke)
-  const int* src_ids4;
   const int2* src_rng;       // [nk][nstrips]: range into src_ids of the sources inside that strip-plane
   const int* src_ids;
   int nsrc; const int* src_off; const int8_t* src_comp; const float* src_amp; const int* src_delay;
@@ -114,10 +110,6 @@ struct fdtd_ctx {
   int P = 0, plane = 0;
   size_t nloc = 0;               // nk*plane
   float* fieldbase[6] = {};      // allocations incl. ghosts
-  float* fieldbase2[6] = {};     // ping-pong partner (one-pass kernel), allocated on first use
-  int2* src_rng4 = nullptr; int* src_ids4 = nullptr;
-  int march_kc = 0;              // one-pass kernel: planes per chunk ($FDTD_MARCH_KC, default 10)
-  bool march_ready = false;
   // P2P mailbox transport
   void* mbox = nullptr; size_t mbox_bytes = 0;     // my mailbox allocation
   bool mbox_fine = false;                          // fine-grained (system-coherent) device memory
@@ -187,9 +179,5 @@ void launch_mur(fdtd_ctx* c, int mode, hipStream_t s);
 void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_t s);   // stand-alone sources + probes
 void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);   // running DFT or time-domain recording of the boxes
 void launch_rec_dft(const float* rec, long npts, int ns, int nfreq, const double* d_tw, double* d_out, hipStream_t s);
-// march.hip: one launch = E half-step + H half-step of all owned planes, current -> next buffers (xy tiles marching through z)
-void launch_step_march(fdtd_ctx* c, long long step, bool probe_block, hipStream_t s);
-void march_counts(const fdtd_ctx* c, int& ntx, int& nty, int& ntz, int& kc);
-void march_tiles_of_cell(const fdtd_ctx* c, int gx, int j, int k, std::vector<int>& out);
 void launch_energy(fdtd_ctx* c, hipStream_t s);
 void choose_tiling(fdtd_ctx* c);

@@ -70,11 +70,9 @@ enum { FDTD_HALO_H_UP = 0, FDTD_HALO_E_DOWN = 1 };   /* Ix,Iy top plane -> rank+
 enum {
   FDTD_FLAG_KERNEL_AUTO   = 0,   /* the two-pass kernels: one E launch + one H launch per step */
   FDTD_FLAG_KERNEL_DIRECT = 1,   /* the same, named explicitly */
-  /* 2, 3 were two one-pass (fused E+H) variants of ABI v1 — per-thread recompute, overlapped LDS tiles: bit-exact, measured
-     slower than the two passes on every workload (profiles/r01), removed in v2: FDTD_E_UNSUPPORTED. */
-  FDTD_FLAG_KERNEL_MARCH  = 4,   /* one-pass leapfrog: 16x16 xy tiles marching through z, planes prefetched into an LDS ring by
-                                    LDS-DMA; ping-pong field buffers.  Single slab, packed class operator, no Mur, no CPML yet:
-                                    FDTD_E_UNSUPPORTED otherwise.  Opt-in. */
+  /* 2..4 were one-pass (fused E+H) variants — per-thread recompute, overlapped LDS tiles, z-marching tiles (round 1), and a
+     z-marching kernel on an LDS-DMA ring (round 2, git history).  All were bit-exact and all measured slower than the two
+     passes (profiles/r01, profiles/r02/one_pass_*); none ships: selecting them is FDTD_E_UNSUPPORTED. */
   FDTD_FLAG_KERNEL_MASK   = 0xF,
   FDTD_FLAG_NO_GRAPH      = 0x10, /* reserved */
   FDTD_FLAG_OVERLAP_ON    = 0x20, /* multi-slab: split sweeps into interior + halo-dependent plane (the default) */

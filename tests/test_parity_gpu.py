@@ -674,32 +674,3 @@ def test_tutorial_scene_gpu_equals_oracle(hip_lib, oracle_lib, tmp_path):
     assert g["f_dip"] == c["f_dip"] and 2.35e9 <= g["f_dip"] <= 2.60e9 and g["dip_dB"] < -10.0
     assert 6.0 <= 10 * np.log10(g["Dmax"]) <= 8.0 and abs(g["Dmax"] - c["Dmax"]) < 1e-6 * c["Dmax"]
     assert rel_l2(g["E_norm"], c["E_norm"]) < 1e-3
-
-
-@pytest.mark.parametrize("shape,kc", [((64, 60, 36), 10), ((53, 47, 31), 7), ((125, 33, 12), 5)])
-def test_march_one_pass_kernel_pec_vs_oracle(hip_lib, oracle_lib, shape, kc, monkeypatch):
-    """The one-pass z-marching kernel (FDTD_FLAG_KERNEL_MARCH: LDS-DMA ring, E and H half-step in one sweep, ping-pong
-    buffers) on PEC boxes — several tile columns in x and y, nx not a multiple of 4 nor of the 60-cell tile, chunk
-    lengths that do not divide nz — against the oracle: fields, port series, chunked runs."""
-    capi = pkg("_capi")
-    monkeypatch.setenv("FDTD_MARCH_KC", str(kc))
-    sh = patch_sim(*shape, boundary="PEC", nr_ts=420, nf2ff=False)
-    so = patch_sim(*shape, boundary="PEC", nr_ts=420, nf2ff=False)
-    eh = sh.build(hip_lib, flags=capi.FLAG_KERNEL_MARCH)
-    eo = so.build(oracle_lib)
-    seeded_fields(eh, 9); seeded_fields(eo, 9)
-    for n in (1, 2, 150, 247):
-        eh.run(n)
-    eo.run(400)
-    fh, fo = eh.fields(), eo.fields()
-    assert np.isfinite(fo).all() and np.abs(fo).max() > 0
-    assert same_values(fh, fo), f"rel L2 {rel_l2(fh, fo):.3e}"
-    (uh, ih), (uo, io) = sh.port_series()[0], so.port_series()[0]
-    assert len(uh) == 400 and rel_l2(uh, uo) < 1e-12 and rel_l2(ih, io) < 1e-12
-
-
-def test_march_refuses_what_it_cannot_do(hip_lib):
-    capi = pkg("_capi")
-    e = patch_sim(40, 40, 30, boundary="MUR", nr_ts=20, nf2ff=False).build(hip_lib, flags=capi.FLAG_KERNEL_MARCH)
-    with pytest.raises(capi.FdtdError, match="one-pass kernel"):
-        e.run(2)

@@ -46,7 +46,7 @@ def main():
                 bspec[2 * a] = bspec[2 * a + 1] = "CPML"
             sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary=bspec, cpml_cells=10, nr_ts=4 * steps + 64,
                                   nf2ff_freqs=[w.f0])
-            eng = sim.build(lib, flags=int(os.environ.get("AB_FLAGS", "0")))   # 4 = one-pass marching kernel
+            eng = sim.build(lib, flags=int(os.environ.get("AB_FLAGS", "0")))
             eng.run(steps // 2)
             t0 = time.perf_counter()
             eng.run(steps)
