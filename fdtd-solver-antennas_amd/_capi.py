@@ -40,7 +40,7 @@ class FdtdProfile(C.Structure):
                 ("steps", C.c_int32), ("fused", C.c_int32), ("ms_event_overhead", C.c_double)]
 
 
-FLAG_KERNEL_AUTO, FLAG_KERNEL_DIRECT, FLAG_NO_GRAPH = 0, 1, 0x10
+FLAG_KERNEL_AUTO, FLAG_KERNEL_DIRECT, FLAG_KERNEL_WAVEFRONT, FLAG_NO_GRAPH = 0, 1, 5, 0x10
 FLAG_OVERLAP_ON, FLAG_OVERLAP_OFF, FLAG_LOOPBACK = 0x20, 0x40, 0x80
 KIND_V, KIND_I = 0, 1
 PHASE_E, PHASE_H = 0, 1

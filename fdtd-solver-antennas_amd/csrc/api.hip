@@ -179,6 +179,8 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   choose_tiling(c);
   p.sweep_rev = getenv("FDTD_NO_SWEEP_REV") ? 0 : 1;
   if (const char* v = getenv("FDTD_OCC_E")) c->occ_e = std::max(0, std::min(16, atoi(v)));
+  if (const char* v = getenv("FDTD_WAVEFRONT")) c->wf_mode = atoi(v) ? 1 : 0;
+  if (const char* v = getenv("FDTD_WF_LAG")) c->wf_lag = std::max(0, std::min(4096, atoi(v)));
   if (const char* v = getenv("FDTD_OCC_H")) c->occ_h = std::max(0, std::min(16, atoi(v)));
   p.src_rng = nullptr; p.src_ids = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
   p.sig = c->sig; p.nsig = 0;
@@ -196,6 +198,7 @@ void fdtd_destroy(fdtd_ctx* c) {
   for (int n = 0; n < 6; ++n) hipFree(c->fieldbase[n]);
   hipFree(c->vv); hipFree(c->vi); hipFree(c->ii); hipFree(c->iv); hipFree(c->ecls); hipFree(c->lut); hipFree(c->met);
   hipFree(c->cpcoef); hipFree(c->xc_tab);
+  hipFree(c->wf_flags); hipFree(c->wf_err);
   for (int n = 0; n < 12; ++n) hipFree(c->psi[n]);
   for (int f = 0; f < 6; ++f) { hipFree(c->mur[f].st[0]); hipFree(c->mur[f].st[1]); }
   hipFree(c->d_mur);
@@ -779,12 +782,57 @@ static int phase_H(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
 static int step_loop_p2p(fdtd_ctx* c, int nsteps, struct ProfEvents* pe);
 static int p2p_check(fdtd_ctx* c);
 
+// One launch per timestep (k_step, kernels.hip): single slab, no Mur faces.  AUTO picks it where it measured faster: grids
+// whose fields do not fit the 256 MiB Infinity Cache (there the H sweep finds what the E sweep just touched in that cache
+// instead of in HBM); FDTD_FLAG_KERNEL_WAVEFRONT / $FDTD_WAVEFRONT=1 force it, FDTD_FLAG_KERNEL_DIRECT / =0 forbid it.
+static bool wavefront_possible(const fdtd_ctx* c) {
+  return c->d.world == 1 && !c->p.p2p && !c->any_mur && c->d.nk >= 2;
+}
+static bool wavefront_active(const fdtd_ctx* c) {
+  const unsigned sel = c->d.flags & FDTD_FLAG_KERNEL_MASK;
+  if (!wavefront_possible(c) || sel == FDTD_FLAG_KERNEL_DIRECT) return false;
+  if (sel == FDTD_FLAG_KERNEL_WAVEFRONT) return true;
+  if (c->wf_mode >= 0) return c->wf_mode != 0;
+  return (size_t)(c->d.nk + 2) * c->plane * 6 * sizeof(float) > ((size_t)FDTD_WF_AUTO_MIB << 20);
+}
+
+static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
+  hipStream_t s = c->stream;
+  for (int n = 0; n < nsteps; ++n) {
+    if (pe) { c->kev0 = pe->e0[n]; c->kev1 = pe->e1[n]; }
+    int r = launch_step_wf(c, c->step, s);
+    c->kev0 = c->kev1 = nullptr;
+    if (r) return r;
+    launch_probes(c, c->step, s);
+    launch_dft(c, FDTD_KIND_V, c->step, s);
+    launch_dft(c, FDTD_KIND_I, c->step, s);
+    c->step++;
+  }
+  HIPCK(c, hipGetLastError());
+  return FDTD_OK;
+}
+// after the stream has drained: did a flag wait of the wavefront schedule time out?
+static int wf_check(fdtd_ctx* c) {
+  if (!c->wf_err) return FDTD_OK;
+  int e = 0;
+  HIPCK(c, hipMemcpy(&e, c->wf_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (e) {
+    hipMemset(c->wf_err, 0, sizeof(int));
+    return fdtd_fail(c, FDTD_E_DEVICE, "wavefront schedule: a block waited more than 2 s for the flag of an earlier block (dispatch not in order?); results of this run are invalid — select FDTD_FLAG_KERNEL_DIRECT");
+  }
+  return FDTD_OK;
+}
+
 static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
-  if ((c->d.flags & FDTD_FLAG_KERNEL_MASK) > FDTD_FLAG_KERNEL_DIRECT)
-    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "kernel selection %u: the one-pass variants were removed (measured slower than the two-pass kernels on every workload)", c->d.flags & FDTD_FLAG_KERNEL_MASK);
+  const unsigned sel = c->d.flags & FDTD_FLAG_KERNEL_MASK;
+  if (sel > FDTD_FLAG_KERNEL_DIRECT && sel != FDTD_FLAG_KERNEL_WAVEFRONT)
+    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "kernel selection %u: the one-pass variants were removed (measured slower than the two-pass kernels on every workload)", sel);
+  if (sel == FDTD_FLAG_KERNEL_WAVEFRONT && !wavefront_possible(c))
+    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "wavefront schedule: single slab (world 1, no halo transport), no Mur faces, at least 2 planes");
   if (c->p.p2p) return step_loop_p2p(c, nsteps, pe);
   const bool multi = c->d.world > 1;
   if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_p2p_attach (mailbox transport), fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
+  if (wavefront_active(c)) return step_loop_wf(c, nsteps, pe);
   const bool fused = sources_fusable(c);
   for (int n = 0; n < nsteps; ++n) {
     int r = phase_E(c, multi, fused, pe, n);
@@ -838,7 +886,7 @@ int fdtd_run(fdtd_ctx* c, int nsteps) {
   HIPCK(c, hipStreamSynchronize(c->stream));
   HIPCK(c, hipStreamSynchronize(c->comm_stream));
   if (c->p.p2p) return p2p_check(c);
-  return FDTD_OK;
+  return wf_check(c);
 }
 
 int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
@@ -889,13 +937,13 @@ int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
     out->ms_event_overhead = 0.0;
     out->ms_update_e = se / nsteps;
     out->ms_update_h = sh / nsteps;
-    out->fused = 0;
-    out->launches_e = out->launches_h = nsteps;
+    out->fused = wavefront_active(c) ? 1 : 0;   // 1: ms_update_e is the one launch of a whole timestep, ms_update_h = 0
+    out->launches_e = nsteps; out->launches_h = out->fused ? 0 : nsteps;
   }
   destroy_all();
   if (r) return r;
   HIPCK(c, e);
-  return FDTD_OK;
+  return wf_check(c);
 }
 
 int fdtd_get_step(fdtd_ctx* c, int64_t* step) {

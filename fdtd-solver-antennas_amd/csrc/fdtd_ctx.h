@@ -24,6 +24,12 @@
 #ifndef FDTD_H_MINBLOCKS
 #define FDTD_H_MINBLOCKS 7
 #endif
+#ifndef FDTD_WF_AUTO_MIB
+#define FDTD_WF_AUTO_MIB 400    // AUTO switches to one launch per timestep when the six field arrays exceed this (Infinity Cache: 256 MiB)
+#endif
+#ifndef FDTD_WF_MINBLOCKS
+#define FDTD_WF_MINBLOCKS 6     // k_step (E and H bodies in one kernel): the H body's budget
+#endif
 
 // Division by a launch-invariant divisor as multiply-high + shift (valid for 0 <= n < 2^31): the block / thread
 // decode of the update kernels otherwise spends ~90 VALU instructions per thread in three 32-bit divisions.
@@ -86,6 +92,8 @@ struct DevParams {
   unsigned* p2p_cnt;         // local arrival counters [2]
   int* p2p_err;              // set when a halo wait timed out
   unsigned long long p2p_limit;   // wall-clock ticks a halo wait may last (10 s)
+  // one launch per timestep (k_step): per-block completion flags of the E blocks [nk][nstrips][nbs], error word, wait limit
+  unsigned* wf_flags; int* wf_err; unsigned long long wf_limit;
   int nt;                    // 1: non-temporal stores for the field outputs (working set beyond the Infinity Cache)
   // fused soft sources (update_E) and probes (extra block of update_E / update_H)
   const int2* src_rng;       // [nk][nstrips]: range into src_ids of the sources inside that strip-plane
@@ -115,6 +123,11 @@ struct fdtd_ctx {
   bool mbox_fine = false;                          // fine-grained (system-coherent) device memory
   void* peer_lo = nullptr; void* peer_hi = nullptr; // neighbours' mailboxes (IPC mappings or in-process pointers)
   bool peer_lo_ipc = false, peer_hi_ipc = false;
+  // one launch per timestep (wavefront schedule, k_step)
+  int wf_mode = -1;              // -1 auto (grids beyond the Infinity Cache), 0 off, 1 on; $FDTD_WAVEFRONT
+  int wf_lag = 0;                // planes the E sweep runs ahead (0: auto); $FDTD_WF_LAG
+  unsigned* wf_flags = nullptr; size_t wf_nflags = 0; int* wf_err = nullptr;
+  unsigned wf_epoch = 0;         // flag value of the last wavefront launch
   int occ_e = 0, occ_h = 0;      // cap on resident blocks per CU of update_E / update_H (0: none); $FDTD_OCC_E / $FDTD_OCC_H
   float *vv = nullptr, *vi = nullptr, *ii = nullptr, *iv = nullptr;
   uint8_t* ecls = nullptr;
@@ -174,6 +187,10 @@ int fdtd_fail(fdtd_ctx* c, int code, const char* fmt, ...);
 int upload_metric_tables(fdtd_ctx* c, const float* emet, const float* hmet);
 void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool fused, bool probe_block, hipStream_t s);
 void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s, bool mur_pre = false);
+// one launch = E and H half-step of all planes (single slab, no Mur, fusable sources); probes are sampled by launch_probes
+int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s);
+int wf_lag_for(const fdtd_ctx* c);
+void launch_probes(fdtd_ctx* c, long long step, hipStream_t s);   // V- and I-probes of `step` in one launch
 int build_mur_table(fdtd_ctx* c);   // after fdtd_set_mur: face table -> device
 void launch_mur(fdtd_ctx* c, int mode, hipStream_t s);
 void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_t s);   // stand-alone sources + probes

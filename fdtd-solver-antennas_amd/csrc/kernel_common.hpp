@@ -139,6 +139,68 @@ __device__ __forceinline__ void decode_block_p2p(const FastDiv& fd_ps, const Fas
   }
 }
 
+// ---- one launch per timestep (k_step): device-scope accesses and the per-block flags ------------------------------------
+// V written by an E block is read by H blocks on other CUs (possibly other XCDs) inside the same launch.  A CU's L1 is
+// never refreshed by another CU's stores and the per-XCD L2s are not coherent with each other, so: write-through (sc1)
+// stores on the producer, sc1 loads to registers on the consumer (MI355X_MICROARCH.md, inter-workgroup visibility).
+// Buffer instructions because the compiler has builtins for them WITH the cache-policy operand (aux 16 = sc1 on gfx950),
+// i.e. it tracks them in its own s_waitcnt bookkeeping and pads the wide store's data hazard itself.
+typedef unsigned v4u_dev __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t DevRsrc;
+__device__ __forceinline__ DevRsrc dev_buf(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);   // raw buffer, no stride, no range limit
+}
+__device__ __forceinline__ float4 ldb4_dev(const DevRsrc b, const unsigned byte_off, const unsigned sdisp) {
+  const v4u_dev r = __builtin_amdgcn_raw_buffer_load_b128(b, (int)byte_off, (int)sdisp, 16);
+  return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
+__device__ __forceinline__ float ldb1_dev(const DevRsrc b, const unsigned byte_off, const unsigned sdisp) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, (int)byte_off, (int)sdisp, 16));
+}
+__device__ __forceinline__ void sto4_dev(float* base, const unsigned e, const float4& v) {
+  const v4u_dev t = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(t, dev_buf(base), (int)(e << 2), 0, 16);
+}
+// E block (k, strip, pb) is done: every wave has its stores acknowledged, the block meets, one lane publishes.
+__device__ __forceinline__ void wf_publish(const DevParams& p, const int k, const int strip, const int pb, const unsigned target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(p.wf_flags + ((size_t)k * p.nstrips + strip) * p.nbs + pb, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// H block (k, strip, pb): wait for the E blocks whose output it reads / whose input it overwrites.  Threads t .. t+255 of
+// the strip-plane read rows j and j+1 (thread t + P4) and the element right of their group (thread t + 1): strip-linear
+// threads [pb*256, pb*256 + 256 + P4] at plane k — running into the next strip's first rows at a strip's end — and the
+// same block at plane k + 1.  One lane per flag, wave 0 polls, the block meets.
+__device__ __forceinline__ void wf_wait(const DevParams& p, const int k, const int strip, const int pb, const unsigned target) {
+  if (threadIdx.x < 64u) {
+    const int hop = 1 + p.P4 / FDTD_BLOCK;
+    const int rows = min(p.tys, p.ny - strip * p.tys);
+    const int T = rows * p.P4;                                   // threads of this strip-plane
+    const int last = pb * FDTD_BLOCK + FDTD_BLOCK + p.P4;        // last strip-linear thread whose data is read
+    const int t = (int)threadIdx.x;
+    const unsigned* f = nullptr;
+    const size_t row = ((size_t)k * p.nstrips + strip) * p.nbs;
+    if (t <= hop) {                                              // same strip, this block and the ones behind it
+      if ((pb + t) * FDTD_BLOCK <= min(last, T - 1)) f = p.wf_flags + row + pb + t;
+    } else if (t <= 2 * hop + 1) {                               // next strip's first blocks
+      const int q = t - hop - 1;
+      if (last >= T && strip + 1 < p.nstrips && q < p.nbs && q * FDTD_BLOCK <= last - T) f = p.wf_flags + row + p.nbs + q;
+    } else if (t == 2 * hop + 2) {                               // plane above
+      if (k + 1 < p.nk) f = p.wf_flags + row + (size_t)p.nstrips * p.nbs + pb;
+    }
+    if (f) {
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__hip_atomic_load(p.wf_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if ((unsigned long long)wall_clock64() - t0 > p.wf_limit) { __hip_atomic_store(p.wf_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // ... and the per-thread part.  Returns false for threads beyond the strip.
 __device__ __forceinline__ bool decode_thread(const DevParams& p, int strip, int pb, int& j, int& i0) {
   const int t = pb * FDTD_BLOCK + (int)threadIdx.x;

@@ -34,26 +34,11 @@ namespace {
 // K1: E half-step
 // ------------------------------------------------------------------------------------------------
 // COEF: 0 raw arrays, 1 class byte per edge, 2 one packed class byte per cell
-template <int COEF, bool PML, bool FUSE, bool P2P>
-__global__ __launch_bounds__(FDTD_BLOCK, (PML || (COEF == 0 && P2P)) ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const FastDiv fd_ps,
-                                                                            const long long step, const int extra, const unsigned nb_main) {
-  extern __shared__ float2 s_lut[];   // coefficient table, lut_n entries (dynamic: scenes use a few dozen of the up to 768)
-  // CPML psi staging (LDS-DMA, 16 KiB); the probe block borrows it for its reduction
-  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : (FUSE ? FDTD_BLOCK / 2 : 1)];
-  __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];   // (b, c, 1/kappa) of the x-layer cells, by psi slot
-  double* const s_red = reinterpret_cast<double*>(s_psi);
-  __shared__ SrcStage s_src;
-  if (FUSE && extra && blockIdx.x == gridDim.x - 1) {   // probe block: H-probes of the step just finished
-    probe_block(p, FDTD_KIND_I, step - 1, s_red);
-    return;
-  }
-  int strip, kk, pb, k;
-  if (P2P) {   // all planes in one launch, the halo-dependent bottom plane last
-    decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, 0, 1, strip, k, pb);
-  } else {
-    decode_block_fd(fd_ps, p.fd_nbs, extra, 0, strip, kk, pb);
-    k = k_begin + kk;
-  }
+// WF: the block is part of a one-launch-per-timestep wavefront (k_step below): V goes out write-through (sc1) and the block
+// publishes its flag when every wave's stores have been acknowledged.
+template <int COEF, bool PML, bool FUSE, bool P2P, bool WF>
+__device__ __forceinline__ void body_E(const DevParams& p, const int strip, const int k, const int pb, const long long step,
+                                       float2* const s_lut, float4* const s_psi, float* const s_xc, SrcStage& s_src, const unsigned wf_target) {
   // coefficient table -> LDS by LDS-DMA, issued FIRST: no staging registers (the kernel has none to spare), and since
   // vector-memory operations retire in order a counted wait below leaves the field loads behind it in flight.
   // Thread t moves entries 2t, 2t+1 (16 bytes; the destination of an LDS-DMA load is lane-linear, so the table lands
@@ -118,7 +103,8 @@ __global__ __launch_bounds__(FDTD_BLOCK, (PML || (COEF == 0 && P2P)) ? FDTD_E_MI
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (!valid) return;
+  if (!WF && !valid) return;
+  if (!WF || valid) {   // (a wavefront block meets once more, at its flag)
 
   if (PML) {
     if (FDTD_PSI_STAGE) {
@@ -185,7 +171,8 @@ __global__ __launch_bounds__(FDTD_BLOCK, (PML || (COEF == 0 && P2P)) ? FDTD_E_MI
         }
       }
     }
-    sto4s(p.nt, p.V[comp], (unsigned)off, v);
+    if (WF) sto4_dev(p.V[comp], (unsigned)off, v);
+    else sto4s(p.nt, p.V[comp], (unsigned)off, v);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (P2P && k == 0 && p.mb_out_E != nullptr) {   // push the new Vx, Vy of the bottom plane into the lower rank's mailbox
@@ -194,6 +181,31 @@ __global__ __launch_bounds__(FDTD_BLOCK, (PML || (COEF == 0 && P2P)) ? FDTD_E_MI
     st4_sys(mb + p.plane, vy);
     p2p_arrive(p.p2p_cnt + 0, (unsigned)p.p2p_waves, p.fl_out_E, (unsigned)step + 1u);
   }
+  }   // valid
+  if (WF) wf_publish(p, k, strip, pb, wf_target);
+}
+
+template <int COEF, bool PML, bool FUSE, bool P2P>
+__global__ __launch_bounds__(FDTD_BLOCK, (PML || (COEF == 0 && P2P)) ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const FastDiv fd_ps,
+                                                                            const long long step, const int extra, const unsigned nb_main) {
+  extern __shared__ float2 s_lut[];   // coefficient table, lut_n entries (dynamic: scenes use a few dozen of the up to 768)
+  // CPML psi staging (LDS-DMA, 16 KiB); the probe block borrows it for its reduction
+  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : (FUSE ? FDTD_BLOCK / 2 : 1)];
+  __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];   // (b, c, 1/kappa) of the x-layer cells, by psi slot
+  double* const s_red = reinterpret_cast<double*>(s_psi);
+  __shared__ SrcStage s_src;
+  if (FUSE && extra && blockIdx.x == gridDim.x - 1) {   // probe block: H-probes of the step just finished
+    probe_block(p, FDTD_KIND_I, step - 1, s_red);
+    return;
+  }
+  int strip, kk, pb, k;
+  if (P2P) {   // all planes in one launch, the halo-dependent bottom plane last
+    decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, 0, 1, strip, k, pb);
+  } else {
+    decode_block_fd(fd_ps, p.fd_nbs, extra, 0, strip, kk, pb);
+    k = k_begin + kk;
+  }
+  body_E<COEF, PML, FUSE, P2P, false>(p, strip, k, pb, step, s_lut, s_psi, s_xc, s_src, 0u);
 }
 
 // Mur "pre" pass (mode 0 of k_mur) of one block: S = V_inner - coeff * V_boundary on the values BEFORE the next E update.
@@ -219,26 +231,10 @@ __device__ __forceinline__ void mur_pre_block(const DevParams& p, const unsigned
 // ------------------------------------------------------------------------------------------------
 // K2: H half-step
 // ------------------------------------------------------------------------------------------------
-template <bool RAW, bool PML, bool P2P>
-__global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const FastDiv fd_ps,
-                                                                            const long long step, const int extra, const unsigned nb_main) {
-  // CPML psi staging (LDS-DMA, 16 KiB); the probe block borrows it for its reduction
-  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : FDTD_BLOCK / 2];
-  __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
-  double* const s_red = reinterpret_cast<double*>(s_psi);
-  if (extra && blockIdx.x >= gridDim.x - (unsigned)extra) {   // the extra blocks at the end of the grid:
-    const unsigned e = blockIdx.x - (gridDim.x - (unsigned)extra);
-    if (e < (unsigned)p.mur_nb) mur_pre_block(p, e);          // Mur pre pass of the next step (V is final, H not read)
-    else probe_block(p, FDTD_KIND_V, step, s_red);            // last one: V-probes of this step
-    return;
-  }
-  int strip, kk, pb, j = 0, i0 = 0, k;
-  if (P2P) {   // all planes in one launch, the halo-dependent top plane last
-    decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, p.nk - 1, 0, strip, k, pb);
-  } else {
-    decode_block_fd(fd_ps, p.fd_nbs, extra, p.sweep_rev, strip, kk, pb);
-    k = k_begin + kk;
-  }
+template <bool RAW, bool PML, bool P2P, bool WF>
+__device__ __forceinline__ void body_H(const DevParams& p, const int strip, const int k, const int pb, const long long step,
+                                       float4* const s_psi, float* const s_xc, const unsigned wf_target) {
+  int j = 0, i0 = 0;
   const bool staged = PML && FDTD_PSI_STAGE;
   const bool xc_lds = staged && p.xc_tab != nullptr;
   if (xc_lds && (int)threadIdx.x < 3 * XC_MAX / 4)   // H-located (b, c, 1/kappa) of the x-layer cells: second half of the table
@@ -246,19 +242,38 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
   // with psi staging the block meets at one barrier (x-layer coefficient table): out-of-range threads of a strip's last
   // block read their block's first group (in range by construction) and leave after it
   const bool valid = decode_thread(p, strip, pb, j, i0);
-  if (!staged && !valid) return;
+  if (!WF && !staged && !valid) return;
   const int off = k * p.plane + (valid ? j * p.P + i0 : 0);
 
   const unsigned uo = (unsigned)off;     // H reads planes k, k+1 only: offsets from plane 0 are never negative
-  const float4 vx = ldo4(p.V[0], uo), vy = ldo4(p.V[1], uo), vz = ldo4(p.V[2], uo);
-  const float4 vz_jp = ldo4(p.V[2] + p.P, uo), vx_jp = ldo4(p.V[0] + p.P, uo);   // neighbour displacements in the scalar bases: one offset VGPR
   const bool dep_in = P2P && k == p.nk - 1 && p.mb_in_E != nullptr;   // k+1 is the upper rank's bottom plane: mailbox
+  float4 vx, vy, vz, vz_jp, vx_jp, ix, iy, iz;
   float4 vy_kp = make_float4(0.f, 0.f, 0.f, 0.f), vx_kp = vy_kp;
-  if (!dep_in) { vy_kp = ldo4(p.V[1] + p.plane, uo); vx_kp = ldo4(p.V[0] + p.plane, uo); }
-  const float vz_ip = ldo1(p.V[2] + 4, uo), vy_ip = ldo1(p.V[1] + 4, uo);
-  float4 ix = ldo4(p.I[0], uo), iy = ldo4(p.I[1], uo), iz = ldo4(p.I[2], uo);
-  if (staged)
-    psi_stage_issue(p, p.psiH, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
+  float vz_ip, vy_ip;
+  if (!WF) {
+    vx = ldo4(p.V[0], uo); vy = ldo4(p.V[1], uo); vz = ldo4(p.V[2], uo);
+    vz_jp = ldo4(p.V[2] + p.P, uo); vx_jp = ldo4(p.V[0] + p.P, uo);   // neighbour displacements in the scalar bases: one offset VGPR
+    if (!dep_in) { vy_kp = ldo4(p.V[1] + p.plane, uo); vx_kp = ldo4(p.V[0] + p.plane, uo); }
+    vz_ip = ldo1(p.V[2] + 4, uo); vy_ip = ldo1(p.V[1] + 4, uo);
+    ix = ldo4(p.I[0], uo); iy = ldo4(p.I[1], uo); iz = ldo4(p.I[2], uo);
+    if (staged)
+      psi_stage_issue(p, p.psiH, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
+  } else {
+    // wavefront block: everything that does not depend on this launch's E blocks first (I, psi), then the flags of the E
+    // blocks this block reads from, then V with device-scope (sc1) loads — they bypass this CU's L1, which no other CU's
+    // store ever refreshes, and are served by L2 / the Infinity Cache, where the write-through stores of body_E land
+    ix = ldo4(p.I[0], uo); iy = ldo4(p.I[1], uo); iz = ldo4(p.I[2], uo);
+    if (staged)
+      psi_stage_issue(p, p.psiH, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
+    wf_wait(p, k, strip, pb, wf_target);
+    if (!staged && !valid) return;
+    const DevRsrc b0 = dev_buf(p.V[0]), b1 = dev_buf(p.V[1]), b2 = dev_buf(p.V[2]);
+    const unsigned bo = uo << 2;
+    vx = ldb4_dev(b0, bo, 0u); vy = ldb4_dev(b1, bo, 0u); vz = ldb4_dev(b2, bo, 0u);
+    vz_jp = ldb4_dev(b2, bo, (unsigned)p.P << 2); vx_jp = ldb4_dev(b0, bo, (unsigned)p.P << 2);
+    vy_kp = ldb4_dev(b1, bo, (unsigned)p.plane << 2); vx_kp = ldb4_dev(b0, bo, (unsigned)p.plane << 2);
+    vz_ip = ldb1_dev(b2, bo, 16u); vy_ip = ldb1_dev(b1, bo, 16u);
+  }
   if (dep_in) {   // E halo of this step
     p2p_wait(p.fl_in + 0, (unsigned)step + 1u, p.p2p_err, p.p2p_limit);
     const float* mb = p.mb_in_E + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
@@ -332,6 +347,69 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
   }
 }
 
+template <bool RAW, bool PML, bool P2P>
+__global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const FastDiv fd_ps,
+                                                                            const long long step, const int extra, const unsigned nb_main) {
+  // CPML psi staging (LDS-DMA, 16 KiB); the probe block borrows it for its reduction
+  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : FDTD_BLOCK / 2];
+  __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
+  double* const s_red = reinterpret_cast<double*>(s_psi);
+  if (extra && blockIdx.x >= gridDim.x - (unsigned)extra) {   // the extra blocks at the end of the grid:
+    const unsigned e = blockIdx.x - (gridDim.x - (unsigned)extra);
+    if (e < (unsigned)p.mur_nb) mur_pre_block(p, e);          // Mur pre pass of the next step (V is final, H not read)
+    else probe_block(p, FDTD_KIND_V, step, s_red);            // last one: V-probes of this step
+    return;
+  }
+  int strip, kk, pb, k;
+  if (P2P) {   // all planes in one launch, the halo-dependent top plane last
+    decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, p.nk - 1, 0, strip, k, pb);
+  } else {
+    decode_block_fd(fd_ps, p.fd_nbs, extra, p.sweep_rev, strip, kk, pb);
+    k = k_begin + kk;
+  }
+  body_H<RAW, PML, P2P, false>(p, strip, k, pb, step, s_psi, s_xc, 0u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1+K2 in ONE launch per timestep: the E sweep runs `lag` planes ahead of the H sweep, coupled by per-block flags.
+// Why: on grids beyond the 256 MiB Infinity Cache the two sweeps of a step each stream all six fields from HBM (72 B per
+// cell and step).  Here H finds the V planes E has just written — and the I planes E has just read — in the Infinity
+// Cache: HBM sees 48 B per cell and step (tools/streams/eh_interleave_probe.hip: -18..-20 % time at 512x512x128 and
+// 800x800x120, nothing at 400x400x80, a loss on cache-resident grids, where the two-launch schedule stays).
+// Dispatch order (block index = 8 * position + XCD group): per XCD group and plane group g: its share of the E blocks of
+// plane g, then its share of the H blocks of plane g - lag.  An H block (k, strip, pb) reads V — and overwrites I values
+// that E blocks read — of: its own cells, the rows above (same strip, or the next strip's first rows) and plane k + 1; it
+// waits for exactly those E blocks' flags (RAW and WAR are the same set).  Every flag it waits for belongs to a block
+// EARLIER in dispatch order (lag >= 1), so with in-order dispatch the wait cannot deadlock; it is bounded all the same
+// (wf_limit ticks, then the error word: the run fails with FDTD_E_DEVICE instead of hanging).
+// Visibility follows MI355X_MICROARCH.md "inter-workgroup visibility": every V store of an E block is write-through (sc1),
+// every wave drains its stores (vmcnt(0)), the block meets, ONE lane publishes the flag with an sc1 store; the consumer's
+// polling wave reads the flags with sc1 loads, the block meets, and EVERY load of V is an sc1 load to registers.
+// ------------------------------------------------------------------------------------------------
+template <int COEF, bool PML>
+__global__ __launch_bounds__(FDTD_BLOCK, FDTD_WF_MINBLOCKS) void k_step(const DevParams p, const long long step, const int lag, const unsigned wf_target,
+                                                                        const unsigned nbp, const FastDiv fd_2m) {
+  extern __shared__ float2 s_lut[];
+  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : 1];
+  __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
+  __shared__ SrcStage s_src;
+  const unsigned b = blockIdx.x, x = b & 7u, pos = b >> 3;
+  const unsigned m = fd_2m.d >> 1;                    // positions per role in a plane group (the largest XCD share of a plane)
+  const unsigned grp = fd_div(pos, fd_2m), w = pos - grp * fd_2m.d;
+  const bool is_h = w >= m;
+  const unsigned r = is_h ? w - m : w;
+  const int k = is_h ? (int)grp - lag : (int)grp;
+  // this XCD group's contiguous share of the plane's nbp = nstrips * nbs blocks
+  const unsigned q = nbp >> 3, rem = nbp & 7u;
+  const unsigned cnt = q + (x < rem ? 1u : 0u), first = x * q + (x < rem ? x : rem);
+  if (k < 0 || k >= p.nk || r >= cnt) return;
+  const unsigned v = first + r;
+  const unsigned strip = fd_div(v, p.fd_nbs);
+  const int pb = (int)(v - strip * p.fd_nbs.d);
+  if (!is_h) body_E<COEF, PML, true, false, true>(p, (int)strip, k, pb, step, s_lut, s_psi, s_xc, s_src, wf_target);
+  else body_H<COEF == 0, PML, false, true>(p, (int)strip, k, pb, step, s_psi, s_xc, wf_target);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: Mur.  One thread per face point and tangential component; blockIdx.y = face*2 + t.
 // ------------------------------------------------------------------------------------------------
@@ -383,6 +461,13 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_post(const DevParams p, const in
     __syncthreads();  // single block: sources land before the probes read
   }
   probe_block(p, kind, step, red);
+}
+
+// V- and I-probes of one step in one launch (wavefront schedule: both fields are final when the step's launch has ended)
+__global__ __launch_bounds__(FDTD_BLOCK) void k_probes(const DevParams p, const long long step) {
+  __shared__ double red[FDTD_BLOCK];
+  probe_block(p, FDTD_KIND_V, step, red);
+  probe_block(p, FDTD_KIND_I, step, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -578,6 +663,58 @@ void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool p
     if (c->have_cpml) launch_H2<false, true>(c, grid, k_begin, nkr, step, extra, s);
     else launch_H2<false, false>(c, grid, k_begin, nkr, step, extra, s);
   }
+}
+
+// ---- one launch per timestep (k_step) ----------------------------------------------------------------------------------
+// E runs `lag` plane groups ahead of H.  A plane group is 2 * 8 * m blocks; an H block should find its flags set when it
+// starts, i.e. the E blocks it waits for should have LEFT the chip: lag = resident blocks / blocks per group + 2
+// (measured with the streaming stand-in: smaller stalls the H blocks, larger gives the Infinity Cache away).
+int wf_lag_for(const fdtd_ctx* c) {
+  if (c->wf_lag > 0) return c->wf_lag;
+  const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs, m = (nbp + 7u) / 8u;
+  const unsigned resident = 256u * FDTD_WF_MINBLOCKS;
+  return (int)((resident + 16u * m - 1u) / (16u * m)) + 2;
+}
+
+template <int COEF, bool PML>
+static void launch_step2(fdtd_ctx* c, long long step, int lag, hipStream_t s) {
+  const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs, m = (nbp + 7u) / 8u;
+  const unsigned lut_bytes = (unsigned)(c->raw_op ? 0 : (c->p.lut_n + 1) / 2) * 16u;
+  const dim3 grid(8u * 2u * m * (unsigned)(c->p.nk + lag));
+  launch_main(c, k_step<COEF, PML>, grid, lut_bytes, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m));
+}
+
+int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s) {
+  const size_t nflags = (size_t)c->p.nk * c->p.nstrips * c->p.nbs;
+  if (!c->wf_flags || c->wf_nflags != nflags) {   // first use (or a new tiling): flags start at 0, the epoch counts the launches
+    if (c->wf_flags) hipFree(c->wf_flags);
+    c->wf_flags = nullptr;
+    HIPCK(c, hipMalloc(&c->wf_flags, nflags * sizeof(unsigned)));
+    HIPCK(c, hipMemsetAsync(c->wf_flags, 0, nflags * sizeof(unsigned), s));
+    if (!c->wf_err) { HIPCK(c, hipMalloc(&c->wf_err, sizeof(int))); HIPCK(c, hipMemsetAsync(c->wf_err, 0, sizeof(int), s)); }
+    c->wf_nflags = nflags;
+    c->wf_epoch = 0;
+  }
+  c->p.wf_flags = c->wf_flags; c->p.wf_err = c->wf_err;
+  c->p.wf_limit = 200000000ull;   // 2 s of the 100 MHz wall clock
+  if (2 * (1 + c->p.P4 / FDTD_BLOCK) + 3 > 64) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "wavefront schedule: rows of more than %d cells", 30 * FDTD_BLOCK * 4);
+  ++c->wf_epoch;
+  const int lag = wf_lag_for(c);
+  const int coef = c->raw_op ? 0 : (c->packed_op ? 2 : 1);
+  if (c->have_cpml) {
+    if (coef == 0) launch_step2<0, true>(c, step, lag, s);
+    else if (coef == 1) launch_step2<1, true>(c, step, lag, s);
+    else launch_step2<2, true>(c, step, lag, s);
+  } else {
+    if (coef == 0) launch_step2<0, false>(c, step, lag, s);
+    else if (coef == 1) launch_step2<1, false>(c, step, lag, s);
+    else launch_step2<2, false>(c, step, lag, s);
+  }
+  return FDTD_OK;
+}
+
+void launch_probes(fdtd_ctx* c, long long step, hipStream_t s) {
+  if (c->nprobe > 0) hipLaunchKernelGGL(k_probes, dim3(1), dim3(FDTD_BLOCK), 0, s, c->p, step);
 }
 
 // face table of the context's Mur faces -> host copy + device copy (DevParams::mur)

@@ -68,11 +68,15 @@ enum { FDTD_HALO_H_UP = 0, FDTD_HALO_E_DOWN = 1 };   /* Ix,Iy top plane -> rank+
 
 /* Kernel selection (fdtd_desc.flags). */
 enum {
-  FDTD_FLAG_KERNEL_AUTO   = 0,   /* the two-pass kernels: one E launch + one H launch per step */
+  FDTD_FLAG_KERNEL_AUTO   = 0,   /* the two-pass kernels (one E launch + one H launch per step); the wavefront schedule below on large single slabs */
   FDTD_FLAG_KERNEL_DIRECT = 1,   /* the same, named explicitly */
   /* 2..4 were one-pass (fused E+H) variants — per-thread recompute, overlapped LDS tiles, z-marching tiles (round 1), and a
      z-marching kernel on an LDS-DMA ring (round 2, git history).  All were bit-exact and all measured slower than the two
      passes (profiles/r01, profiles/r02/one_pass_*); none ships: selecting them is FDTD_E_UNSUPPORTED. */
+  FDTD_FLAG_KERNEL_WAVEFRONT = 5, /* ONE launch per timestep: the E sweep runs a few planes ahead of the H sweep, coupled by per-block
+                                    flags, so that H reads what E just touched from the Infinity Cache instead of HBM.  Single slab,
+                                    no Mur faces (else FDTD_E_UNSUPPORTED).  AUTO picks it for grids beyond the Infinity Cache; DIRECT
+                                    never does.  Results are identical to the two-pass kernels bit for bit. */
   FDTD_FLAG_KERNEL_MASK   = 0xF,
   FDTD_FLAG_NO_GRAPH      = 0x10, /* reserved */
   FDTD_FLAG_OVERLAP_ON    = 0x20, /* multi-slab: split sweeps into interior + halo-dependent plane (the default) */

@@ -674,3 +674,39 @@ def test_tutorial_scene_gpu_equals_oracle(hip_lib, oracle_lib, tmp_path):
     assert g["f_dip"] == c["f_dip"] and 2.35e9 <= g["f_dip"] <= 2.60e9 and g["dip_dB"] < -10.0
     assert 6.0 <= 10 * np.log10(g["Dmax"]) <= 8.0 and abs(g["Dmax"] - c["Dmax"]) < 1e-6 * c["Dmax"]
     assert rel_l2(g["E_norm"], c["E_norm"]) < 1e-3
+
+
+@pytest.mark.parametrize("lag", [0, 1, 3])
+@pytest.mark.parametrize("shape,bc,use_classes", [((64, 60, 36), "CPML", True), ((53, 47, 31), "CPML", False),
+                                                  ((125, 33, 12), "PEC", True), ((1100, 24, 16), "CPML", True)])
+def test_wavefront_schedule_vs_oracle(hip_lib, oracle_lib, shape, bc, use_classes, lag, monkeypatch):
+    """One launch per timestep (FDTD_FLAG_KERNEL_WAVEFRONT: E sweep `lag` planes ahead of the H sweep, per-block flags,
+    write-through V stores, sc1 V loads) against the oracle: fields bit for bit, port series, NF2FF boxes, chunked runs.
+    Shapes: several strips and several blocks per strip, nx not a multiple of 4, rows longer than a block (P4 > 256 threads
+    -> the flag set reaches two blocks on), fewer planes than the lag; lag 0 = the library's own choice."""
+    capi = pkg("_capi")
+    if lag:
+        monkeypatch.setenv("FDTD_WF_LAG", str(lag))
+    kw = dict(boundary=bc, cpml_cells=4 if shape[2] < 20 else 6, nr_ts=420, use_classes=use_classes, nf2ff=bc == "CPML")
+    sh, so = patch_sim(*shape, **kw), patch_sim(*shape, **kw)
+    eh = sh.build(hip_lib, flags=capi.FLAG_KERNEL_WAVEFRONT)
+    eo = so.build(oracle_lib)
+    seeded_fields(eh, 11); seeded_fields(eo, 11)
+    for n in (1, 2, 150, 247):
+        eh.run(n)
+    eo.run(400)
+    fh, fo = eh.fields(), eo.fields()
+    assert np.isfinite(fo).all() and np.abs(fo).max() > 0
+    assert same_values(fh, fo), f"rel L2 {rel_l2(fh, fo):.3e}"
+    (uh, ih), (uo, io) = sh.port_series()[0], so.port_series()[0]
+    assert len(uh) == 400 and rel_l2(uh, uo) < 1e-12 and rel_l2(ih, io) < 1e-12
+    if bc == "CPML":
+        for a, b in zip(sh.nf2ff_boxes(), so.nf2ff_boxes()):
+            assert rel_l2(a, b) < 1e-12
+
+
+def test_wavefront_schedule_refuses_what_it_cannot_do(hip_lib):
+    capi = pkg("_capi")
+    e = patch_sim(40, 40, 30, boundary="MUR", nr_ts=20, nf2ff=False).build(hip_lib, flags=capi.FLAG_KERNEL_WAVEFRONT)
+    with pytest.raises(capi.FdtdError, match="wavefront"):
+        e.run(2)
