@@ -204,8 +204,13 @@ def roofline_block(workload, eng, prof, world, host_transport, ms_timestep):
     own_cells = eng.nk * eng.ny * eng.nx
     algo_bytes = ALGO_BYTES_PER_CELL_HALFSTEP * own_cells
     ms_e, ms_h = prof.ms_update_e, prof.ms_update_h
-    dom = "update_E" if ms_e >= ms_h else "update_H"
-    ms_dom = max(ms_e, ms_h)
+    one_launch = bool(getattr(prof, "fused", 0))     # wavefront schedule (k_step): E and H half-step of all planes in ONE launch
+    if one_launch:
+        dom, ms_dom, ms_h = "step", ms_e, 0.0
+        algo_bytes *= 2                               # 36 B per cell and half-step, two half-steps per launch
+    else:
+        dom = "update_E" if ms_e >= ms_h else "update_H"
+        ms_dom = max(ms_e, ms_h)
     if host_transport or not (ms_dom == ms_dom and ms_dom > 0):
         # host halo transport: kernels are launched one half-step at a time, nothing to profile
         return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
@@ -218,6 +223,7 @@ def roofline_block(workload, eng, prof, world, host_transport, ms_timestep):
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
            "traffic_source": source, "kernel": dom, "ms_update_E": round(ms_e, 5), "ms_update_H": round(ms_h, 5),
            "algorithmic_bytes_per_launch": algo_bytes,
+           "schedule": "one launch per timestep (k_step: E sweep a few planes ahead of the H sweep)" if one_launch else "two launches per timestep",
            "kernel_timing": "dispatch begin/end timestamps (start/stop events on every main launch), nothing subtracted",
            "ms_per_timestep_profiled": round(ms_ts, 5),
            # the 256 MiB Infinity Cache holds the whole working set of the smaller grids: their 'HBM' rate is a cache rate
@@ -271,7 +277,7 @@ def pmc_traffic(workload, kernel, world):
     try:
         data = json.load(open(files[-1]))["per_launch_traffic"]
         for name, rec in data.items():
-            if kernel.replace("update_", "k_update_") in name:
+            if kernel.replace("update_", "k_update_").replace("step", "k_step") in name:
                 return round(rec["total_bytes"]), ("committed rocprofv3 --pmc passes, not measured in this run: "
                                                    + os.path.relpath(files[-1], ROOT))
     except (OSError, KeyError, ValueError):

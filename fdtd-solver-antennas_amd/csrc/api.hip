@@ -179,6 +179,8 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   choose_tiling(c);
   p.sweep_rev = getenv("FDTD_NO_SWEEP_REV") ? 0 : 1;
   if (const char* v = getenv("FDTD_OCC_E")) c->occ_e = std::max(0, std::min(16, atoi(v)));
+  if (const char* v = getenv("FDTD_NT")) p.nt = atoi(v) ? 1 : 0;                       // experiments
+  if (const char* v = getenv("FDTD_OCC_WF")) c->occ_wf = std::max(0, std::min(16, atoi(v)));
   if (const char* v = getenv("FDTD_WAVEFRONT")) c->wf_mode = atoi(v) ? 1 : 0;
   if (const char* v = getenv("FDTD_WF_LAG")) c->wf_lag = std::max(0, std::min(4096, atoi(v)));
   if (const char* v = getenv("FDTD_OCC_H")) c->occ_h = std::max(0, std::min(16, atoi(v)));

@@ -25,7 +25,7 @@
 #define FDTD_H_MINBLOCKS 7
 #endif
 #ifndef FDTD_WF_AUTO_MIB
-#define FDTD_WF_AUTO_MIB 400    // AUTO switches to one launch per timestep when the six field arrays exceed this (Infinity Cache: 256 MiB)
+#define FDTD_WF_AUTO_MIB 256    // AUTO switches to one launch per timestep when the six field arrays exceed the Infinity Cache (256 MiB)
 #endif
 #ifndef FDTD_WF_MINBLOCKS
 #define FDTD_WF_MINBLOCKS 6     // k_step (E and H bodies in one kernel): the H body's budget
@@ -128,6 +128,7 @@ struct fdtd_ctx {
   int wf_lag = 0;                // planes the E sweep runs ahead (0: auto); $FDTD_WF_LAG
   unsigned* wf_flags = nullptr; size_t wf_nflags = 0; int* wf_err = nullptr;
   unsigned wf_epoch = 0;         // flag value of the last wavefront launch
+  int occ_wf = 0;                // cap on resident blocks per CU of k_step (0: none); $FDTD_OCC_WF
   int occ_e = 0, occ_h = 0;      // cap on resident blocks per CU of update_E / update_H (0: none); $FDTD_OCC_E / $FDTD_OCC_H
   float *vv = nullptr, *vi = nullptr, *ii = nullptr, *iv = nullptr;
   uint8_t* ecls = nullptr;

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
 // ------------------------------------------------------------------------------------------------
 template <int COEF, bool PML>
 __global__ __launch_bounds__(FDTD_BLOCK, FDTD_WF_MINBLOCKS) void k_step(const DevParams p, const long long step, const int lag, const unsigned wf_target,
-                                                                        const unsigned nbp, const FastDiv fd_2m) {
+                                                                        const unsigned nbp, const FastDiv fd_2m, const int down) {
   extern __shared__ float2 s_lut[];
   __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : 1];
   __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
@@ -398,11 +398,14 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_WF_MINBLOCKS) void k_step(const De
   const unsigned grp = fd_div(pos, fd_2m), w = pos - grp * fd_2m.d;
   const bool is_h = w >= m;
   const unsigned r = is_h ? w - m : w;
-  const int k = is_h ? (int)grp - lag : (int)grp;
+  int k = is_h ? (int)grp - lag : (int)grp;
   // this XCD group's contiguous share of the plane's nbp = nstrips * nbs blocks
   const unsigned q = nbp >> 3, rem = nbp & 7u;
   const unsigned cnt = q + (x < rem ? 1u : 0u), first = x * q + (x < rem ? x : rem);
   if (k < 0 || k >= p.nk || r >= cnt) return;
+  // odd steps walk the planes downwards: a step starts on the planes the previous one touched last (still in the Infinity
+  // Cache).  The flags an H block waits for — planes k and k + 1 — are earlier in dispatch order in either direction.
+  if (down) k = p.nk - 1 - k;
   const unsigned v = first + r;
   const unsigned strip = fd_div(v, p.fd_nbs);
   const int pb = (int)(v - strip * p.fd_nbs.d);
@@ -672,7 +675,7 @@ void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool p
 int wf_lag_for(const fdtd_ctx* c) {
   if (c->wf_lag > 0) return c->wf_lag;
   const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs, m = (nbp + 7u) / 8u;
-  const unsigned resident = 256u * FDTD_WF_MINBLOCKS;
+  const unsigned resident = 256u * (unsigned)(c->occ_wf > 0 && c->occ_wf < FDTD_WF_MINBLOCKS ? c->occ_wf : FDTD_WF_MINBLOCKS);
   return (int)((resident + 16u * m - 1u) / (16u * m)) + 2;
 }
 
@@ -681,7 +684,9 @@ static void launch_step2(fdtd_ctx* c, long long step, int lag, hipStream_t s) {
   const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs, m = (nbp + 7u) / 8u;
   const unsigned lut_bytes = (unsigned)(c->raw_op ? 0 : (c->p.lut_n + 1) / 2) * 16u;
   const dim3 grid(8u * 2u * m * (unsigned)(c->p.nk + lag));
-  launch_main(c, k_step<COEF, PML>, grid, lut_bytes, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m));
+  const unsigned pad = lut_bytes + lds_pad(c->occ_wf, (PML && FDTD_PSI_STAGE ? 20480u : 2560u) + lut_bytes);
+  launch_main(c, k_step<COEF, PML>, grid, pad, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m),
+              (c->p.sweep_rev && (step & 1)) ? 1 : 0);
 }
 
 int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s) {
