@@ -28,6 +28,13 @@ __device__ __forceinline__ void st4s(const int nt, float* p, const float4& v) {
 __device__ __forceinline__ void sto4s(const int nt, float* base, const unsigned e, const float4& v) {
   st4s(nt, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (e << 2)), v);
 }
+// 8-byte load through the scalar cache from a wave-uniform address (data the host wrote before the launch); waits only for
+// scalar-memory returns, never for the vector loads in flight
+__device__ __forceinline__ int2 sload_int2(const int2* q) {
+  unsigned long long v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(q));
+  return make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
+}
 __device__ __forceinline__ float4 sub4(const float4& a, const float4& b) {
   return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
 }
@@ -355,7 +362,13 @@ __device__ __forceinline__ void cpml_x4(const DevParams& p, int eh, int i0, int 
 // ox / oz: element offsets into the psi arrays, -1 when the group is outside that layer.
 __device__ __forceinline__ int psi_off_x(const DevParams& p, const int k, const int j, const int i0) {   // -1: outside the x layers
   if (!(i0 < p.pml_lo[0] || i0 >= p.pml_hi[0])) return -1;   // both bounds are multiples of 4: all four cells or none
-  return (k * p.ny + j) * p.nslot[0] + (i0 < p.pml_lo[0] ? i0 : i0 - p.pml_hi[0] + p.pml_hi_slot[0]);
+  // product and sum kept apart (the empty asm): fused, hipcc emits v_mad_u64_u32 with an UNDEFINED high half of the 64-bit
+  // addend, picks a register a field load is still in flight to for it, and guards that false dependency with
+  // s_waitcnt vmcnt(0) — in front of the staged psi loads, i.e. every wave with an x-layer lane (all of them) waited for its
+  // field loads before it issued its psi loads
+  int row = (k * p.ny + j) * p.nslot[0];
+  asm volatile("" : "+v"(row));
+  return row + (i0 < p.pml_lo[0] ? i0 : i0 - p.pml_hi[0] + p.pml_hi_slot[0]);
 }
 __device__ __forceinline__ int psi_off_z(const DevParams& p, const int k, const int j, const int i0) {
   const int sz = pml_slot(p, 2, k);

@@ -73,11 +73,14 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
   if (!dep_in) { iy_km = ldo4(I1 - p.plane, uo); ix_km = ldo4(I0 - p.plane, uo); }
   const float iz_im = ldo1(I2 - 1, uo), iy_im = ldo1(I1 - 1, uo);
   float4 vx = ldo4(p.V[0] - p.plane, uo), vy = ldo4(p.V[1] - p.plane, uo), vz = ldo4(p.V[2] - p.plane, uo);
-  // soft sources inside this strip-plane (block-uniform range; almost always empty)
+  // Soft sources inside this strip-plane (block-uniform range; almost always empty).  The range comes by an explicit SCALAR
+  // load: left to the compiler this uniform load sits behind the LDS-DMA statements (asm, "memory"), cannot be proven
+  // unclobbered and becomes a vector load + s_waitcnt vmcnt(0) in the middle of the load phase — every wave then waited for
+  // all its field loads before it issued the staged psi loads, the second round trip the staging exists to avoid.
   int2 srng = make_int2(0, 0);
   if (FUSE && p.nsrc > 0) {
-    srng = p.src_rng[k * p.nstrips + strip];
-    stage_sources(p, p.src_ids, srng.x, min(srng.y - srng.x, FDTD_BLOCK), step, s_src);
+    srng = sload_int2(p.src_rng + (k * p.nstrips + strip));
+    if (srng.y > srng.x) stage_sources(p, p.src_ids, srng.x, min(srng.y - srng.x, FDTD_BLOCK), step, s_src);
   }
   if (PML && FDTD_PSI_STAGE)   // psi of the x / z layers: LDS-DMA right behind the field loads (kernel_common.hpp)
     psi_stage_issue(p, p.psiE, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);

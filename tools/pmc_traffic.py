@@ -37,7 +37,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         raw[k][ctr] = {"launches": len(v), "mean": sum(v) / len(v)}
 per = {}
 for k, v in raw.items():
-    if "k_update" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+    if ("k_update" in k or "k_step" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         rd = v["FETCH_SIZE"]["mean"] * 1024.0 * 2.0      # KiB, x2 gfx950 correction
         wr = v["WRITE_SIZE"]["mean"] * 1024.0
         per[k] = {"read_bytes_corrected": rd, "write_bytes": wr, "total_bytes": rd + wr}

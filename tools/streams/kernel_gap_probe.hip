@@ -1,0 +1,175 @@
+// Where do the update kernels lose against a pure streaming kernel with the same algorithmic bytes?  (NS: 58 us per PEC
+// timestep against 44.6 us for the stand-in of eh_interleave_probe.hip.)  The stand-in grows the real kernels' features one
+// at a time; two launches per step (E forwards, H backwards), six in-place arrays.
+//   bit 0: in-plane neighbour loads (E: row j-1 of two components + element i-1 of two; H: row j+1, element i+4)
+//   bit 1: one class byte per cell + a 768-entry (vv, m) table staged in LDS by LDS-DMA + the barrier behind the loads (E)
+//   bit 2: 1-D metric tables (E: 3 float4 by x + 6 scalars; H: the same)
+//   bit 3: strip-major block order inside each XCD's range (strips of 16 rows marching through z) instead of plane-major
+//   bit 4: 7 resident blocks per CU instead of 8 (LDS padding)
+//   bit 5 / bit 6: 100 / 200 extra dependent-free VALU instructions per thread between loads and stores
+// hipcc -O3 --offload-arch=gfx950 -o gap_probe kernel_gap_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+struct Arr { float* V[3]; float* I[3]; const unsigned char* cls; const float2* lut; const float* met; };
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; return a; }
+__device__ __forceinline__ float4 mul4(float4 a, const float4& b) { a.x *= b.x; a.y *= b.y; a.z *= b.z; a.w *= b.w; return a; }
+
+template <int F, int WHICH>
+__global__ __launch_bounds__(256) void k_sweep(const Arr a, const int nx, const int ny, const int nz, const int rev) {
+  extern __shared__ float2 s_lut[];
+  const int P4 = nx / 4, plane = nx * ny;
+  const int tys = 16, nstrips = (ny + tys - 1) / tys, nbs = (tys * P4 + 255) / 256;
+  const unsigned nb = gridDim.x, b = blockIdx.x;
+  const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u;
+  unsigned pos = b >> 3;
+  if (rev) pos = (xcd < r ? q : q - 1u) - pos;
+  const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  int strip, k, pb;
+  if (F & 8) {   // strip-major: strip, then z, then block within the strip-plane
+    const unsigned per_strip = (unsigned)nz * nbs;
+    strip = v / per_strip; const unsigned rem = v - strip * per_strip; k = rem / nbs; pb = rem - k * nbs;
+  } else {       // plane-major: z, then strip, then block
+    const unsigned per_plane = (unsigned)nstrips * nbs;
+    k = v / per_plane; const unsigned rem = v - k * per_plane; strip = rem / nbs; pb = rem - strip * nbs;
+  }
+  if ((F & 2) && WHICH == 0) {   // LUT -> LDS by LDS-DMA (6 KiB), issued first
+    const unsigned w_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)s_lut + (threadIdx.x >> 6) * 1024u);
+    const float* src = reinterpret_cast<const float*>(a.lut) + 4 * threadIdx.x;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(w_lds) : "memory");
+    if (threadIdx.x < 128) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src + 1024), "s"(w_lds + 4096u) : "memory");
+  }
+  const int t = pb * 256 + threadIdx.x;
+  const int rows = min(tys, ny - strip * tys);
+  const bool valid = t < rows * P4;
+  const int jj = valid ? t / P4 : 0, i0 = valid ? (t - jj * P4) * 4 : 0, j = strip * tys + jj;
+  const size_t off = (size_t)(k + 1) * plane + (size_t)j * nx + i0;
+  float4 o0, o1, o2;
+  if (WHICH == 0) {
+    float4 v0 = ld4(a.V[0] + off), v1 = ld4(a.V[1] + off), v2 = ld4(a.V[2] + off);
+    const float4 i0v = ld4(a.I[0] + off), i1v = ld4(a.I[1] + off), i2v = ld4(a.I[2] + off);
+    const float4 i0m = ld4(a.I[0] + off - plane), i1m = ld4(a.I[1] + off - plane);
+    float4 d0 = add4(i1v, i1m), d1 = add4(i0v, i0m), d2 = i2v;
+    if (F & 1) {
+      const float4 i2j = ld4(a.I[2] + off - nx), i0j = ld4(a.I[0] + off - nx);
+      const float s2 = a.I[2][off - 1], s1 = a.I[1][off - 1];
+      d0 = add4(d0, i2j); d2 = add4(d2, i0j); d1.x += s2; d2.x += s1;
+    }
+    uchar4 cc = make_uchar4(0, 0, 0, 0);
+    if (F & 2) {
+      cc = *reinterpret_cast<const uchar4*>(a.cls + off);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (!valid) return;
+    if (F & 4) {
+      const float4 ex0 = ld4(a.met + i0), ex1 = ld4(a.met + 4096 + i0), ex2 = ld4(a.met + 8192 + i0);
+      const float m0 = a.met[12288 + j] * a.met[16384 + k], m1 = a.met[20480 + j] * a.met[24576 + k], m2 = a.met[28672 + j] * a.met[32768 + k];
+      d0 = mul4(d0, make_float4(ex0.x * m0, ex0.y * m0, ex0.z * m0, ex0.w * m0));
+      d1 = mul4(d1, make_float4(ex1.x * m1, ex1.y * m1, ex1.z * m1, ex1.w * m1));
+      d2 = mul4(d2, make_float4(ex2.x * m2, ex2.y * m2, ex2.z * m2, ex2.w * m2));
+    }
+    if (F & 2) {
+      const float2 l0 = s_lut[3 * cc.x], l1 = s_lut[3 * cc.y + 1], l2 = s_lut[3 * cc.z + 2], l3 = s_lut[3 * cc.w];
+      v0 = mul4(v0, make_float4(l0.x, l1.x, l2.x, l3.x)); d0 = mul4(d0, make_float4(l0.y, l1.y, l2.y, l3.y));
+    }
+    if (F & 96) {
+      const int n = ((F & 32) ? 8 : 0) + ((F & 64) ? 16 : 0);
+#pragma unroll
+      for (int q = 0; q < n; ++q) {   // 12 VALU ops per round on independent accumulators
+        d0.x = __builtin_fmaf(d0.x, 1.0001f, v0.x); d0.y = __builtin_fmaf(d0.y, 1.0001f, v0.y); d0.z = __builtin_fmaf(d0.z, 1.0001f, v0.z); d0.w = __builtin_fmaf(d0.w, 1.0001f, v0.w);
+        d1.x = __builtin_fmaf(d1.x, 1.0001f, v1.x); d1.y = __builtin_fmaf(d1.y, 1.0001f, v1.y); d1.z = __builtin_fmaf(d1.z, 1.0001f, v1.z); d1.w = __builtin_fmaf(d1.w, 1.0001f, v1.w);
+        d2.x = __builtin_fmaf(d2.x, 1.0001f, v2.x); d2.y = __builtin_fmaf(d2.y, 1.0001f, v2.y); d2.z = __builtin_fmaf(d2.z, 1.0001f, v2.z); d2.w = __builtin_fmaf(d2.w, 1.0001f, v2.w);
+      }
+    }
+    o0 = add4(v0, d0); o1 = add4(v1, d1); o2 = add4(v2, d2);
+    st4(a.V[0] + off, o0); st4(a.V[1] + off, o1); st4(a.V[2] + off, o2);
+  } else {
+    if (!valid) return;
+    const float4 v0 = ld4(a.V[0] + off), v1 = ld4(a.V[1] + off), v2 = ld4(a.V[2] + off);
+    const float4 v0p = ld4(a.V[0] + off + plane), v1p = ld4(a.V[1] + off + plane);
+    float4 i0v = ld4(a.I[0] + off), i1v = ld4(a.I[1] + off), i2v = ld4(a.I[2] + off);
+    float4 d0 = add4(v1, v1p), d1 = add4(v0, v0p), d2 = v2;
+    if (F & 1) {
+      const float4 v2j = ld4(a.V[2] + off + nx), v0j = ld4(a.V[0] + off + nx);
+      const float s2 = a.V[2][off + 4], s1 = a.V[1][off + 4];
+      d0 = add4(d0, v2j); d2 = add4(d2, v0j); d1.w += s2; d2.w += s1;
+    }
+    if (F & 4) {
+      const float4 ex0 = ld4(a.met + i0), ex1 = ld4(a.met + 4096 + i0), ex2 = ld4(a.met + 8192 + i0);
+      const float m0 = a.met[12288 + j] * a.met[16384 + k], m1 = a.met[20480 + j] * a.met[24576 + k], m2 = a.met[28672 + j] * a.met[32768 + k];
+      d0 = mul4(d0, make_float4(ex0.x * m0, ex0.y * m0, ex0.z * m0, ex0.w * m0));
+      d1 = mul4(d1, make_float4(ex1.x * m1, ex1.y * m1, ex1.z * m1, ex1.w * m1));
+      d2 = mul4(d2, make_float4(ex2.x * m2, ex2.y * m2, ex2.z * m2, ex2.w * m2));
+    }
+    if (F & 96) {
+      const int n = ((F & 32) ? 8 : 0) + ((F & 64) ? 16 : 0);
+#pragma unroll
+      for (int q = 0; q < n; ++q) {
+        d0.x = __builtin_fmaf(d0.x, 1.0001f, v0.x); d0.y = __builtin_fmaf(d0.y, 1.0001f, v0.y); d0.z = __builtin_fmaf(d0.z, 1.0001f, v0.z); d0.w = __builtin_fmaf(d0.w, 1.0001f, v0.w);
+        d1.x = __builtin_fmaf(d1.x, 1.0001f, v1.x); d1.y = __builtin_fmaf(d1.y, 1.0001f, v1.y); d1.z = __builtin_fmaf(d1.z, 1.0001f, v1.z); d1.w = __builtin_fmaf(d1.w, 1.0001f, v1.w);
+        d2.x = __builtin_fmaf(d2.x, 1.0001f, v2.x); d2.y = __builtin_fmaf(d2.y, 1.0001f, v2.y); d2.z = __builtin_fmaf(d2.z, 1.0001f, v2.z); d2.w = __builtin_fmaf(d2.w, 1.0001f, v2.w);
+      }
+    }
+    o0 = add4(i0v, d0); o1 = add4(i1v, d1); o2 = add4(i2v, d2);
+    st4(a.I[0] + off, o0); st4(a.I[1] + off, o1); st4(a.I[2] + off, o2);
+  }
+}
+
+template <int F>
+void run(const char* name, int nx, int ny, int nz) {
+  const size_t plane = (size_t)nx * ny, n = plane * (nz + 2);
+  Arr a;
+  for (int c = 0; c < 3; ++c) { hipMalloc(&a.V[c], n * 4); hipMemset(a.V[c], 0, n * 4); hipMalloc(&a.I[c], n * 4); hipMemset(a.I[c], 0, n * 4); }
+  unsigned char* cls; hipMalloc(&cls, n); hipMemset(cls, 1, n); a.cls = cls;
+  float2* lut; hipMalloc(&lut, 1024 * 8); hipMemset(lut, 0, 1024 * 8); a.lut = lut;
+  float* met; hipMalloc(&met, 40960 * 4); hipMemset(met, 0, 40960 * 4); a.met = met;
+  const int P4 = nx / 4, tys = 16, nstrips = (ny + tys - 1) / tys, nbs = (tys * P4 + 255) / 256;
+  const unsigned grid = (unsigned)nstrips * nbs * nz;
+  const unsigned lds = ((F & 2) ? 6144u : 0u) + ((F & 16) ? 22 * 1024u : 0u);   // 7 blocks per CU: 160 KiB / 7 ~ 22.8 KiB each
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int reps = 40;
+  for (int it = -4; it < reps; ++it) {
+    if (it == 0) hipEventRecord(e0);
+    hipLaunchKernelGGL((k_sweep<F, 0>), dim3(grid), dim3(256), lds, 0, a, nx, ny, nz, 0);
+    hipLaunchKernelGGL((k_sweep<F, 1>), dim3(grid), dim3(256), (F & 16) ? 22 * 1024u : 0u, 0, a, nx, ny, nz, 1);
+  }
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double cells = (double)nx * ny * nz;
+  printf("%s %dx%dx%d features %2d [%s%s%s%s%s]: %7.1f us/step  %6.1f Gcells/s  [%s]\n", name, nx, ny, nz, F, (F & 1) ? "nbr " : "", (F & 2) ? "cls+lut " : "",
+         (F & 4) ? "metric " : "", (F & 8) ? "strip-major " : "", (F & 16) ? "occ7 " : "", ms / reps * 1e3, cells / (ms / reps * 1e-3) / 1e9,
+         hipGetErrorString(hipGetLastError()));
+  fflush(stdout);
+  for (int c = 0; c < 3; ++c) { hipFree(a.V[c]); hipFree(a.I[c]); }
+  hipFree(cls); hipFree(lut); hipFree(met);
+}
+
+int main() {
+  struct { const char* name; int nx, ny, nz; } grids[] = {{"NS", 300, 300, 60}, {"C3", 400, 400, 80}};
+  for (auto& g : grids) {
+    run<0>(g.name, g.nx, g.ny, g.nz);
+    run<1>(g.name, g.nx, g.ny, g.nz);
+    run<2>(g.name, g.nx, g.ny, g.nz);
+    run<4>(g.name, g.nx, g.ny, g.nz);
+    run<8>(g.name, g.nx, g.ny, g.nz);
+    run<16>(g.name, g.nx, g.ny, g.nz);
+    run<1 | 8>(g.name, g.nx, g.ny, g.nz);
+    run<1 | 2 | 4>(g.name, g.nx, g.ny, g.nz);
+    run<1 | 2 | 4 | 8>(g.name, g.nx, g.ny, g.nz);
+    run<1 | 2 | 4 | 8 | 16>(g.name, g.nx, g.ny, g.nz);
+    run<32>(g.name, g.nx, g.ny, g.nz);
+    run<64>(g.name, g.nx, g.ny, g.nz);
+    run<96>(g.name, g.nx, g.ny, g.nz);
+    run<31 | 32>(g.name, g.nx, g.ny, g.nz);
+    run<31 | 64>(g.name, g.nx, g.ny, g.nz);
+    run<31 | 96>(g.name, g.nx, g.ny, g.nz);
+  }
+  return 0;
+}
