@@ -271,7 +271,7 @@ def pmc_traffic(workload, kernel, world):
     import glob
     if world != 1:
         return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{workload}_*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{workload}*.json")))
     if not files:
         return None, None
     try:
