@@ -710,3 +710,39 @@ def test_wavefront_schedule_refuses_what_it_cannot_do(hip_lib):
     e = patch_sim(40, 40, 30, boundary="MUR", nr_ts=20, nf2ff=False).build(hip_lib, flags=capi.FLAG_KERNEL_WAVEFRONT)
     with pytest.raises(capi.FdtdError, match="wavefront"):
         e.run(2)
+
+
+@pytest.mark.parametrize("shape,tys", [((37, 300, 10), 0), ((37, 300, 10), 4), ((64, 60, 36), 40), ((53, 47, 31), 5),
+                                       ((1028, 9, 9), 0), ((260, 18, 40), 7)])
+def test_wavefront_schedule_odd_tilings_equal_two_launches(hip_lib, shape, tys, monkeypatch):
+    """The flag sets of the one-launch schedule under unusual tilings — 25 rows per block, one-row strips' worth of blocks,
+    strips of 4 / 5 / 7 / 40 rows ($FDTD_TYS), a short last strip, rows longer than a block, more blocks per plane group than
+    planes — against the two-launch schedule of the same library (which the rest of the suite pins to the oracle): every
+    field value and the port series after 300 steps from seeded random fields."""
+    capi = pkg("_capi")
+    if tys:
+        monkeypatch.setenv("FDTD_TYS", str(tys))
+    out = []
+    for flags in (capi.FLAG_KERNEL_DIRECT, capi.FLAG_KERNEL_WAVEFRONT):
+        s = patch_sim(*shape, boundary="CPML", cpml_cells=3, nr_ts=320, nf2ff=False)
+        e = s.build(hip_lib, flags=flags)
+        seeded_fields(e, 21)
+        e.run(300)
+        out.append((s, e))
+    (s1, e1), (s2, e2) = out
+    f1, f2 = e1.fields(), e2.fields()
+    assert np.isfinite(f1).all() and np.abs(f1).max() > 0
+    assert same_values(f1, f2), f"rel L2 {rel_l2(f2, f1):.3e}"
+    assert rel_l2(s2.port_series()[0][0], s1.port_series()[0][0]) < 1e-12
+
+
+def test_auto_picks_the_one_launch_schedule_only_beyond_the_infinity_cache(hip_lib):
+    """AUTO: two launches per timestep on a cache-resident grid, one on a grid whose six field arrays exceed 256 MiB
+    (fdtd_profile.fused); DIRECT never, WAVEFRONT always."""
+    capi = pkg("_capi")
+    small = patch_sim(64, 60, 36, nr_ts=40, nf2ff=False)
+    assert small.build(hip_lib).run_profiled(4).fused == 0
+    assert small.build(hip_lib, flags=capi.FLAG_KERNEL_WAVEFRONT).run_profiled(4).fused == 1
+    big = patch_sim(400, 400, 82, nr_ts=40, nf2ff=False)          # 6 x 84 planes x 640 KB = 323 MB
+    assert big.build(hip_lib).run_profiled(4).fused == 1
+    assert big.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT).run_profiled(4).fused == 0
