@@ -434,7 +434,10 @@ def run_linked(engines, nsteps: int):
     for lo, hi in zip(engines[:-1], engines[1:]):
         lo._ck(lib.fdtd_link(lo._ctx, hi._ctx), "link")
     arr = (C.c_void_p * len(engines))(*[e._ctx for e in engines])
-    engines[0]._ck(lib.fdtd_run_linked(arr, len(engines), int(nsteps)), "run_linked")
+    rc = lib.fdtd_run_linked(arr, len(engines), int(nsteps))
+    if rc != 0:   # the message sits in the context that failed, not necessarily the first one
+        msgs = [f"rank {r}: {m.decode()}" for r, e in enumerate(engines) if (m := lib.fdtd_last_error(e._ctx))]
+        raise FdtdError(f"run_linked failed ({rc}): " + "; ".join(msgs))
 
 
 def comm_unique_id(lib: C.CDLL) -> bytes:

@@ -200,7 +200,7 @@ void fdtd_destroy(fdtd_ctx* c) {
   for (int n = 0; n < 6; ++n) hipFree(c->fieldbase[n]);
   hipFree(c->vv); hipFree(c->vi); hipFree(c->ii); hipFree(c->iv); hipFree(c->ecls); hipFree(c->lut); hipFree(c->met);
   hipFree(c->cpcoef); hipFree(c->xc_tab);
-  hipFree(c->wf_flags); hipFree(c->wf_err);
+  hipFree(c->wf_flags); hipFree(c->wf_err); hipFree(c->wf_flagsH); hipFree(c->wf_prb_sp); hipFree(c->wf_prb_blk); hipFree(c->wf_prb_rng);
   for (int n = 0; n < 12; ++n) hipFree(c->psi[n]);
   for (int f = 0; f < 6; ++f) { hipFree(c->mur[f].st[0]); hipFree(c->mur[f].st[1]); }
   hipFree(c->d_mur);
@@ -479,6 +479,7 @@ int fdtd_add_probe(fdtd_ctx* c, int kind, int n, const int64_t* idx, const int8_
   HIPCK(c, to_device(&d_cm, cm));
   HIPCK(c, to_device(&d_w, ww));
   p.off = d_off; p.comp = d_cm; p.w = d_w;
+  c->h_prb_off[c->nprobe] = off; c->wf_prb_dirty = true;
   const size_t cap = std::max(c->d.max_steps, 1);
   HIPCK(c, hipMalloc(&p.series, cap * sizeof(double)));
   HIPCK(c, hipMemset(p.series, 0, cap * sizeof(double)));
@@ -788,24 +789,27 @@ static int p2p_check(fdtd_ctx* c);
 // whose fields do not fit the 256 MiB Infinity Cache (there the H sweep finds what the E sweep just touched in that cache
 // instead of in HBM); FDTD_FLAG_KERNEL_WAVEFRONT / $FDTD_WAVEFRONT=1 force it, FDTD_FLAG_KERNEL_DIRECT / =0 forbid it.
 static bool wavefront_possible(const fdtd_ctx* c) {
-  return c->d.world == 1 && !c->p.p2p && !c->any_mur && c->d.nk >= 2;
+  return (c->d.world == 1 || c->p.p2p) && !c->any_mur && c->d.nk >= 2;
 }
 static bool wavefront_active(const fdtd_ctx* c) {
   const unsigned sel = c->d.flags & FDTD_FLAG_KERNEL_MASK;
   if (!wavefront_possible(c) || sel == FDTD_FLAG_KERNEL_DIRECT) return false;
   if (sel == FDTD_FLAG_KERNEL_WAVEFRONT) return true;
   if (c->wf_mode >= 0) return c->wf_mode != 0;
+  // (thin slabs of a decomposed grid, where every block of a timestep is resident at once, were the other candidate: measured
+  // on an 8-plane north-star slab whose halos go to itself, one launch takes 30-37 us per step against 28 us for two — the
+  // chain E block -> flag -> poll -> sc1 loads -> H block is longer than a kernel boundary.  Not chosen.)
   return (size_t)(c->d.nk + 2) * c->plane * 6 * sizeof(float) > ((size_t)FDTD_WF_AUTO_MIB << 20);
 }
 
 static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
+  HIPCK(c, hipSetDevice(c->d.device));
   hipStream_t s = c->stream;
   for (int n = 0; n < nsteps; ++n) {
     if (pe) { c->kev0 = pe->e0[n]; c->kev1 = pe->e1[n]; }
     int r = launch_step_wf(c, c->step, s);
     c->kev0 = c->kev1 = nullptr;
     if (r) return r;
-    launch_probes(c, c->step, s);
     launch_dft(c, FDTD_KIND_V, c->step, s);
     launch_dft(c, FDTD_KIND_I, c->step, s);
     c->step++;
@@ -830,7 +834,7 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   if (sel > FDTD_FLAG_KERNEL_DIRECT && sel != FDTD_FLAG_KERNEL_WAVEFRONT)
     return fdtd_fail(c, FDTD_E_UNSUPPORTED, "kernel selection %u: the one-pass variants were removed (measured slower than the two-pass kernels on every workload)", sel);
   if (sel == FDTD_FLAG_KERNEL_WAVEFRONT && !wavefront_possible(c))
-    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "wavefront schedule: single slab (world 1, no halo transport), no Mur faces, at least 2 planes");
+    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "wavefront schedule: single slab or slabs on the p2p mailbox transport, no Mur faces, at least 2 planes");
   if (c->p.p2p) return step_loop_p2p(c, nsteps, pe);
   const bool multi = c->d.world > 1;
   if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_p2p_attach (mailbox transport), fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
@@ -867,8 +871,11 @@ static int p2p_enqueue_H(fdtd_ctx* c, ProfEvents* pe, int n) {
   launch_dft(c, FDTD_KIND_I, c->step, c->stream);
   return FDTD_OK;
 }
+static bool wavefront_active(const fdtd_ctx* c);
+static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe);
 static int step_loop_p2p(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   if (c->any_mur || c->d.nk < 2) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "p2p transport: needs >= 2 planes per slab and no Mur faces");
+  if (wavefront_active(c)) return step_loop_wf(c, nsteps, pe);   // one launch per timestep, halos inside it as well
   for (int n = 0; n < nsteps; ++n) {
     int r;
     if ((r = p2p_enqueue_E(c, pe, n)) || (r = p2p_enqueue_H(c, pe, n))) return r;
@@ -887,7 +894,7 @@ int fdtd_run(fdtd_ctx* c, int nsteps) {
   if (r) return r;
   HIPCK(c, hipStreamSynchronize(c->stream));
   HIPCK(c, hipStreamSynchronize(c->comm_stream));
-  if (c->p.p2p) return p2p_check(c);
+  if (c->p.p2p) { r = p2p_check(c); if (r) return r; }
   return wf_check(c);
 }
 
@@ -1344,12 +1351,21 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
   const bool multi = n > 1 || (ctxs[0]->d.flags & FDTD_FLAG_LOOPBACK);
   if (ctxs[0]->p.p2p) {   // mailbox transport between contexts of this process: interleave the ranks' launches
     for (int r = 0; r < n; ++r) if (!ctxs[r]->p.p2p || ctxs[r]->any_mur) return fdtd_fail(ctxs[r], FDTD_E_STATE, "fdtd_run_linked: every context must use the p2p transport (no Mur)");
+    const bool wf = wavefront_active(ctxs[0]);
+    for (int r = 1; r < n; ++r) if (wavefront_active(ctxs[r]) != wf) return fdtd_fail(ctxs[r], FDTD_E_STATE, "fdtd_run_linked: the contexts disagree on the kernel schedule (set fdtd_desc.flags alike)");
     for (int s = 0; s < nsteps; ++s) {
       int rc;
+      if (wf) {   // one launch per timestep and slab, TOP rank first: a slab's launch waits (H of its top plane) for the E
+        // blocks of plane 0 in the launch of the rank above for the SAME step.  Streams of one process may share a hardware
+        // queue, where a launch waits for the one submitted before it: the launch waited for must be the earlier one
+        // (bottom rank first timed out in exactly that way).  What a launch needs from the rank below belongs to the previous step.
+        for (int r = n - 1; r >= 0; --r) { if ((rc = step_loop_wf(ctxs[r], 1, nullptr))) return rc; }
+        continue;
+      }
       for (int r = 0; r < n; ++r) if ((rc = p2p_enqueue_E(ctxs[r], nullptr, 0))) return rc;
       for (int r = 0; r < n; ++r) { if ((rc = p2p_enqueue_H(ctxs[r], nullptr, 0))) return rc; ctxs[r]->step++; }
     }
-    for (int r = 0; r < n; ++r) {
+    for (int r = 0; r < n && !wf; ++r) {
       fdtd_ctx* c = ctxs[r];
       HIPCK(c, hipSetDevice(c->d.device));
       if (nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);
@@ -1360,6 +1376,7 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
       HIPCK(c, hipStreamSynchronize(c->stream));
       int rc = p2p_check(c);
       if (rc) return rc;
+      if ((rc = wf_check(c))) return rc;
     }
     return FDTD_OK;
   }

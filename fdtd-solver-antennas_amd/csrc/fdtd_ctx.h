@@ -28,7 +28,7 @@
 #define FDTD_WF_AUTO_MIB 256    // AUTO switches to one launch per timestep when the six field arrays exceed the Infinity Cache (256 MiB)
 #endif
 #ifndef FDTD_WF_MINBLOCKS
-#define FDTD_WF_MINBLOCKS 6     // k_step (E and H bodies in one kernel): the H body's budget
+#define FDTD_WF_MINBLOCKS 7     // k_step (E and H bodies in one kernel)
 #endif
 
 // Division by a launch-invariant divisor as multiply-high + shift (valid for 0 <= n < 2^31): the block / thread
@@ -94,6 +94,9 @@ struct DevParams {
   unsigned long long p2p_limit;   // wall-clock ticks a halo wait may last (10 s)
   // one launch per timestep (k_step): per-block completion flags of the E blocks [nk][nstrips][nbs], error word, wait limit
   unsigned* wf_flags; int* wf_err; unsigned long long wf_limit;
+  // ... and the probes of a step as the LAST blocks of its launch: H blocks of strip-planes that hold I-probe cells store
+  // write-through and publish flags of their own (wf_flagsH, same indexing); probe q waits for the blocks wf_prb_blk[wf_prb_rng[q]]
+  unsigned* wf_flagsH; const int* wf_prb_sp; const int* wf_prb_blk; const int2* wf_prb_rng;
   int nt;                    // 1: non-temporal stores for the field outputs (working set beyond the Infinity Cache)
   // fused soft sources (update_E) and probes (extra block of update_E / update_H)
   const int2* src_rng;       // [nk][nstrips]: range into src_ids of the sources inside that strip-plane
@@ -128,6 +131,9 @@ struct fdtd_ctx {
   int wf_lag = 0;                // planes the E sweep runs ahead (0: auto); $FDTD_WF_LAG
   unsigned* wf_flags = nullptr; size_t wf_nflags = 0; int* wf_err = nullptr;
   unsigned wf_epoch = 0;         // flag value of the last wavefront launch
+  unsigned* wf_flagsH = nullptr; int* wf_prb_sp = nullptr; int* wf_prb_blk = nullptr; int2* wf_prb_rng = nullptr;
+  bool wf_prb_dirty = true;      // probe tables of the wavefront launch need rebuilding (a probe was added)
+  std::vector<int> h_prb_off[FDTD_MAX_PROBES];   // local offsets of every probe's cells (host copy)
   int occ_wf = 0;                // cap on resident blocks per CU of k_step (0: none); $FDTD_OCC_WF
   int occ_e = 0, occ_h = 0;      // cap on resident blocks per CU of update_E / update_H (0: none); $FDTD_OCC_E / $FDTD_OCC_H
   float *vv = nullptr, *vi = nullptr, *ii = nullptr, *iv = nullptr;
@@ -191,7 +197,7 @@ void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool p
 // one launch = E and H half-step of all planes (single slab, no Mur, fusable sources); probes are sampled by launch_probes
 int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s);
 int wf_lag_for(const fdtd_ctx* c);
-void launch_probes(fdtd_ctx* c, long long step, hipStream_t s);   // V- and I-probes of `step` in one launch
+void launch_probes(fdtd_ctx* c, long long step, hipStream_t s);   // V- and I-probes of `step` in one launch (stand-alone form)
 int build_mur_table(fdtd_ctx* c);   // after fdtd_set_mur: face table -> device
 void launch_mur(fdtd_ctx* c, int mode, hipStream_t s);
 void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_t s);   // stand-alone sources + probes

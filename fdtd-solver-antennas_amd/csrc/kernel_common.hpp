@@ -168,12 +168,50 @@ __device__ __forceinline__ void sto4_dev(float* base, const unsigned e, const fl
   const v4u_dev t = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
   __builtin_amdgcn_raw_buffer_store_b128(t, dev_buf(base), (int)(e << 2), 0, 16);
 }
-// E block (k, strip, pb) is done: every wave has its stores acknowledged, the block meets, one lane publishes.
-__device__ __forceinline__ void wf_publish(const DevParams& p, const int k, const int strip, const int pb, const unsigned target) {
+// Block (k, strip, pb) is done: every wave has its stores acknowledged, the block meets, one lane publishes.
+__device__ __forceinline__ void wf_publish(const DevParams& p, unsigned* flags, const int k, const int strip, const int pb, const unsigned target) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0)
-    __hip_atomic_store(p.wf_flags + ((size_t)k * p.nstrips + strip) * p.nbs + pb, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(flags + ((size_t)k * p.nstrips + strip) * p.nbs + pb, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int sload_int(const int* q) {
+  int v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(q));
+  return v;
+}
+// bounded poll of one flag (any lane)
+__device__ __forceinline__ void wf_poll(const DevParams& p, const unsigned* f, const unsigned target) {
+  const unsigned long long t0 = wall_clock64();
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(2);
+    if (__hip_atomic_load(p.wf_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    if ((unsigned long long)wall_clock64() - t0 > p.wf_limit) { __hip_atomic_store(p.wf_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+  }
+}
+// Probe q of step `step` as one of the LAST blocks of the step's launch: wait for the blocks that own its cells (E flags for
+// a V-probe, H flags for an I-probe: those H blocks stored write-through), read the cells with device-scope loads, reduce
+// with probe_block's tree (identical sums).
+__device__ __forceinline__ void wf_probe_tail(const DevParams& p, const int q, const long long step, const unsigned target, double* red) {
+  if (step < 0 || step >= p.max_steps) return;
+  const DevProbe pr = p.probes[q];
+  const int2 rng = p.wf_prb_rng[q];
+  const unsigned* flags = pr.kind == FDTD_KIND_V ? p.wf_flags : p.wf_flagsH;
+  for (int e = rng.x + (int)threadIdx.x; e < rng.y; e += FDTD_BLOCK) wf_poll(p, flags + p.wf_prb_blk[e], target);
+  __syncthreads();
+  double s = 0.0;
+  for (int e = threadIdx.x; e < pr.n; e += FDTD_BLOCK) {
+    const float* F = (pr.kind == FDTD_KIND_V ? p.V[pr.comp[e]] : p.I[pr.comp[e]]);
+    const unsigned bits = __hip_atomic_load(reinterpret_cast<const unsigned*>(F + pr.off[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s = fma((double)pr.w[e], (double)__uint_as_float(bits), s);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = FDTD_BLOCK / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) pr.series[step] = red[0];
 }
 // H block (k, strip, pb): wait for the E blocks whose output it reads / whose input it overwrites.  Threads t .. t+255 of
 // the strip-plane read rows j and j+1 (thread t + P4) and the element right of their group (thread t + 1): strip-linear
@@ -196,14 +234,7 @@ __device__ __forceinline__ void wf_wait(const DevParams& p, const int k, const i
     } else if (t == 2 * hop + 2) {                               // plane above
       if (k + 1 < p.nk) f = p.wf_flags + row + (size_t)p.nstrips * p.nbs + pb;
     }
-    if (f) {
-      const unsigned long long t0 = wall_clock64();
-      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(2);
-        if (__hip_atomic_load(p.wf_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if ((unsigned long long)wall_clock64() - t0 > p.wf_limit) { __hip_atomic_store(p.wf_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      }
-    }
+    if (f) wf_poll(p, f, target);
   }
   __syncthreads();
 }

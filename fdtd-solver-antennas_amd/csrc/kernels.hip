@@ -25,6 +25,8 @@
 // Float32 operation order is pinned with explicit fmaf (compiled with -ffp-contract=off) and is
 // identical to oracle/fdtd_oracle.c, so results are compared bit for bit.
 #include <hip/hip_ext.h>
+#include <algorithm>
+#include <vector>
 
 #include "kernel_common.hpp"
 
@@ -185,7 +187,7 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
     p2p_arrive(p.p2p_cnt + 0, (unsigned)p.p2p_waves, p.fl_out_E, (unsigned)step + 1u);
   }
   }   // valid
-  if (WF) wf_publish(p, k, strip, pb, wf_target);
+  if (WF) wf_publish(p, p.wf_flags, k, strip, pb, wf_target);
 }
 
 template <int COEF, bool PML, bool FUSE, bool P2P>
@@ -269,12 +271,11 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
     if (staged)
       psi_stage_issue(p, p.psiH, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
     wf_wait(p, k, strip, pb, wf_target);
-    if (!staged && !valid) return;
     const DevRsrc b0 = dev_buf(p.V[0]), b1 = dev_buf(p.V[1]), b2 = dev_buf(p.V[2]);
     const unsigned bo = uo << 2;
     vx = ldb4_dev(b0, bo, 0u); vy = ldb4_dev(b1, bo, 0u); vz = ldb4_dev(b2, bo, 0u);
     vz_jp = ldb4_dev(b2, bo, (unsigned)p.P << 2); vx_jp = ldb4_dev(b0, bo, (unsigned)p.P << 2);
-    vy_kp = ldb4_dev(b1, bo, (unsigned)p.plane << 2); vx_kp = ldb4_dev(b0, bo, (unsigned)p.plane << 2);
+    if (!dep_in) { vy_kp = ldb4_dev(b1, bo, (unsigned)p.plane << 2); vx_kp = ldb4_dev(b0, bo, (unsigned)p.plane << 2); }
     vz_ip = ldb1_dev(b2, bo, 16u); vy_ip = ldb1_dev(b1, bo, 16u);
   }
   if (dep_in) {   // E halo of this step
@@ -292,8 +293,12 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
   if (staged) {   // one barrier, where every wave has its loads anyway (see update_E): x-layer coefficient table + staged psi are in LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!valid) return;
+    if (!WF && !valid) return;
   }
+  // wavefront block of a strip-plane that holds I-probe cells: its I goes out write-through and it publishes a flag of its
+  // own, for the probe blocks at the end of the launch (wf_probe_tail); such a block meets once more, so nobody leaves early
+  const bool pub = WF && p.wf_prb_sp != nullptr && sload_int(p.wf_prb_sp + (k * p.nstrips + strip)) != 0;
+  if (!WF || valid) {
 
   if (PML) {
     if (FDTD_PSI_STAGE) {
@@ -339,15 +344,16 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
     iz = make_float4(iz.x + (hx2.x * m2) * (dz1.x - dz2.x), iz.y + (hx2.y * m2) * (dz1.y - dz2.y),
                      iz.z + (hx2.z * m2) * (dz1.z - dz2.z), iz.w + (hx2.w * m2) * (dz1.w - dz2.w));
   }
-  sto4s(p.nt, p.I[0], uo, ix);
-  sto4s(p.nt, p.I[1], uo, iy);
-  sto4s(p.nt, p.I[2], uo, iz);
+  if (pub) { sto4_dev(p.I[0], uo, ix); sto4_dev(p.I[1], uo, iy); sto4_dev(p.I[2], uo, iz); }
+  else { sto4s(p.nt, p.I[0], uo, ix); sto4s(p.nt, p.I[1], uo, iy); sto4s(p.nt, p.I[2], uo, iz); }
   if (P2P && k == p.nk - 1 && p.mb_out_H != nullptr) {   // push the new Ix, Iy of the top plane into the upper rank's mailbox
     float* mb = p.mb_out_H + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
     st4_sys(mb, ix);
     st4_sys(mb + p.plane, iy);
     p2p_arrive(p.p2p_cnt + 1, (unsigned)p.p2p_waves, p.fl_out_H, (unsigned)step + 1u);
   }
+  }   // valid
+  if (pub) wf_publish(p, p.wf_flagsH, k, strip, pb, wf_target);
 }
 
 template <bool RAW, bool PML, bool P2P>
@@ -389,14 +395,18 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
 // every wave drains its stores (vmcnt(0)), the block meets, ONE lane publishes the flag with an sc1 store; the consumer's
 // polling wave reads the flags with sc1 loads, the block meets, and EVERY load of V is an sc1 load to registers.
 // ------------------------------------------------------------------------------------------------
-template <int COEF, bool PML>
+template <int COEF, bool PML, bool P2P>
 __global__ __launch_bounds__(FDTD_BLOCK, FDTD_WF_MINBLOCKS) void k_step(const DevParams p, const long long step, const int lag, const unsigned wf_target,
-                                                                        const unsigned nbp, const FastDiv fd_2m, const int down) {
+                                                                        const unsigned nbp, const FastDiv fd_2m, const int down, const unsigned nmain) {
   extern __shared__ float2 s_lut[];
-  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : 1];
+  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : FDTD_BLOCK / 2];   // (the probe blocks borrow it for their reduction)
   __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
   __shared__ SrcStage s_src;
   const unsigned b = blockIdx.x, x = b & 7u, pos = b >> 3;
+  if (b >= nmain) {   // the last blocks of the launch: one per probe
+    wf_probe_tail(p, (int)(b - nmain), step, wf_target, reinterpret_cast<double*>(s_psi));
+    return;
+  }
   const unsigned m = fd_2m.d >> 1;                    // positions per role in a plane group (the largest XCD share of a plane)
   const unsigned grp = fd_div(pos, fd_2m), w = pos - grp * fd_2m.d;
   const bool is_h = w >= m;
@@ -412,8 +422,11 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_WF_MINBLOCKS) void k_step(const De
   const unsigned v = first + r;
   const unsigned strip = fd_div(v, p.fd_nbs);
   const int pb = (int)(v - strip * p.fd_nbs.d);
-  if (!is_h) body_E<COEF, PML, true, false, true>(p, (int)strip, k, pb, step, s_lut, s_psi, s_xc, s_src, wf_target);
-  else body_H<COEF == 0, PML, false, true>(p, (int)strip, k, pb, step, s_psi, s_xc, wf_target);
+  // P2P (mailbox halo transport, upwards only): E of plane 0 — the first blocks of the launch — takes its k-1 neighbours from
+  // the lower rank's mailbox and pushes its result down; H of the top plane — the last H blocks — takes k+1 from the upper
+  // rank's mailbox (that rank's E blocks of plane 0 are the first of ITS launch) and pushes its result up.
+  if (!is_h) body_E<COEF, PML, true, P2P, true>(p, (int)strip, k, pb, step, s_lut, s_psi, s_xc, s_src, wf_target);
+  else body_H<COEF == 0, PML, P2P, true>(p, (int)strip, k, pb, step, s_psi, s_xc, wf_target);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -696,28 +709,73 @@ int wf_lag_for(const fdtd_ctx* c) {
   return (int)((resident + 16u * m - 1u) / (16u * m)) + 2;
 }
 
-template <int COEF, bool PML>
-static void launch_step2(fdtd_ctx* c, long long step, int lag, hipStream_t s) {
+template <int COEF, bool PML, bool P2P>
+static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s) {
   const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs, m = (nbp + 7u) / 8u;
   const unsigned lut_bytes = (unsigned)(c->raw_op ? 0 : (c->p.lut_n + 1) / 2) * 16u;
-  const dim3 grid(8u * 2u * m * (unsigned)(c->p.nk + lag));
+  const unsigned nmain = 8u * 2u * m * (unsigned)(c->p.nk + lag);
+  const dim3 grid(nmain + (unsigned)c->nprobe);
   const unsigned pad = lut_bytes + lds_pad(c->occ_wf, (PML && FDTD_PSI_STAGE ? 20480u : 2560u) + lut_bytes);
-  launch_main(c, k_step<COEF, PML>, grid, pad, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m),
-              (c->p.sweep_rev && (step & 1)) ? 1 : 0);
+  launch_main(c, k_step<COEF, PML, P2P>, grid, pad, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m),
+              (!P2P && c->p.sweep_rev && (step & 1)) ? 1 : 0, nmain);
+}
+template <int COEF, bool PML>
+static void launch_step2(fdtd_ctx* c, long long step, int lag, hipStream_t s) {
+  if (c->p.p2p) launch_step3<COEF, PML, true>(c, step, lag, s);
+  else launch_step3<COEF, PML, false>(c, step, lag, s);
+}
+
+// Probe tables of the wavefront launch: which blocks own each probe's cells (the probe block waits for their flags), and which
+// strip-planes hold I-probe cells (their H blocks store write-through and publish).  Rebuilt when a probe was added.
+static int build_wf_probe_tables(fdtd_ctx* c, hipStream_t s) {
+  const int nsp = c->p.nk * c->p.nstrips;
+  std::vector<int> sp(nsp, 0), blk;
+  std::vector<int2> rng(FDTD_MAX_PROBES, make_int2(0, 0));
+  for (int q = 0; q < c->nprobe; ++q) {
+    std::vector<int> mine;
+    for (int off : c->h_prb_off[q]) {
+      const int k = off / c->plane, r = off - k * c->plane, j = r / c->P, i = r - j * c->P;
+      const int strip = j / c->p.tys, t = (j - strip * c->p.tys) * c->p.P4 + i / 4;
+      mine.push_back((k * c->p.nstrips + strip) * c->p.nbs + t / FDTD_BLOCK);
+      if (c->probe[q].kind == FDTD_KIND_I) sp[k * c->p.nstrips + strip] = 1;
+    }
+    std::sort(mine.begin(), mine.end());
+    mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
+    rng[q] = make_int2((int)blk.size(), (int)(blk.size() + mine.size()));
+    blk.insert(blk.end(), mine.begin(), mine.end());
+  }
+  if (blk.empty()) blk.push_back(0);
+  HIPCK(c, hipStreamSynchronize(s));     // nothing in flight reads the old tables
+  hipFree(c->wf_prb_sp); hipFree(c->wf_prb_blk); hipFree(c->wf_prb_rng);
+  c->wf_prb_sp = nullptr; c->wf_prb_blk = nullptr; c->wf_prb_rng = nullptr;
+  HIPCK(c, hipMalloc(&c->wf_prb_sp, sp.size() * sizeof(int)));
+  HIPCK(c, hipMalloc(&c->wf_prb_blk, blk.size() * sizeof(int)));
+  HIPCK(c, hipMalloc(&c->wf_prb_rng, rng.size() * sizeof(int2)));
+  HIPCK(c, hipMemcpy(c->wf_prb_sp, sp.data(), sp.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCK(c, hipMemcpy(c->wf_prb_blk, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCK(c, hipMemcpy(c->wf_prb_rng, rng.data(), rng.size() * sizeof(int2), hipMemcpyHostToDevice));
+  c->wf_prb_dirty = false;
+  return FDTD_OK;
 }
 
 int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s) {
   const size_t nflags = (size_t)c->p.nk * c->p.nstrips * c->p.nbs;
   if (!c->wf_flags || c->wf_nflags != nflags) {   // first use (or a new tiling): flags start at 0, the epoch counts the launches
     if (c->wf_flags) hipFree(c->wf_flags);
-    c->wf_flags = nullptr;
+    if (c->wf_flagsH) hipFree(c->wf_flagsH);
+    c->wf_flags = nullptr; c->wf_flagsH = nullptr;
     HIPCK(c, hipMalloc(&c->wf_flags, nflags * sizeof(unsigned)));
     HIPCK(c, hipMemsetAsync(c->wf_flags, 0, nflags * sizeof(unsigned), s));
+    HIPCK(c, hipMalloc(&c->wf_flagsH, nflags * sizeof(unsigned)));
+    HIPCK(c, hipMemsetAsync(c->wf_flagsH, 0, nflags * sizeof(unsigned), s));
+    c->wf_prb_dirty = true;
     if (!c->wf_err) { HIPCK(c, hipMalloc(&c->wf_err, sizeof(int))); HIPCK(c, hipMemsetAsync(c->wf_err, 0, sizeof(int), s)); }
     c->wf_nflags = nflags;
     c->wf_epoch = 0;
   }
+  if (c->wf_prb_dirty) { int r = build_wf_probe_tables(c, s); if (r) return r; }
   c->p.wf_flags = c->wf_flags; c->p.wf_err = c->wf_err;
+  c->p.wf_flagsH = c->wf_flagsH; c->p.wf_prb_sp = c->wf_prb_sp; c->p.wf_prb_blk = c->wf_prb_blk; c->p.wf_prb_rng = c->wf_prb_rng;
   c->p.wf_limit = 200000000ull;   // 2 s of the 100 MHz wall clock
   if (2 * (1 + c->p.P4 / FDTD_BLOCK) + 3 > 64) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "wavefront schedule: rows of more than %d cells", 30 * FDTD_BLOCK * 4);
   ++c->wf_epoch;

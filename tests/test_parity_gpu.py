@@ -389,17 +389,21 @@ def _attach_p2p(engs, selftest=False):
         assert not errs, errs
 
 
+@pytest.mark.parametrize("schedule", ["two_launches", "one_launch"])
 @pytest.mark.parametrize("world", [2, 3, 5])
-def test_p2p_mailbox_transport_slabs_equal_one_slab(hip_lib, world):
+def test_p2p_mailbox_transport_slabs_equal_one_slab(hip_lib, world, schedule):
     """P2P mailbox transport (halos pushed by the update kernels into the neighbour's mailbox, step-counter flags,
     dependent plane scheduled last): `world` slabs in this process on one GPU — each on its own stream, coupled only
-    through the mailboxes — must reproduce the single-slab run bit for bit, over several fdtd_run_linked calls."""
+    through the mailboxes — must reproduce the single-slab run bit for bit, over several fdtd_run_linked calls.
+    one_launch: every slab steps with ONE launch per timestep (k_step with the mailbox protocol inside: E of plane 0 first,
+    H of the top plane last), which AUTO picks for thin slabs."""
     capi = pkg("_capi")
+    flags = capi.FLAG_KERNEL_DIRECT if schedule == "two_launches" else capi.FLAG_KERNEL_WAVEFRONT
     s1 = patch_sim(56, 52, 34, nr_ts=260)
-    e1 = s1.build(hip_lib)
+    e1 = s1.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT)
     e1.run(260)
     sims = [patch_sim(56, 52, 34, nr_ts=260) for _ in range(world)]
-    engs = [s.build(hip_lib, rank=r, world=world) for r, s in enumerate(sims)]
+    engs = [s.build(hip_lib, rank=r, world=world, flags=flags) for r, s in enumerate(sims)]
     _attach_p2p(engs, selftest=(world == 3))
     for n in (1, 100, 159):
         capi.run_linked(engs, n)
