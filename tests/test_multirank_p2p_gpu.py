@@ -17,8 +17,10 @@ SHAPE = (48, 44, 36)
 STEPS = 150
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, one_launch):
     import torch.distributed as dist
+    if one_launch:      # every rank steps with ONE launch per timestep, the mailbox protocol inside it (read at fdtd_create)
+        os.environ["FDTD_WAVEFRONT"] = "1"
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -45,13 +47,13 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_p2p_ranks_in_separate_processes_equal_one_slab(hip_lib, tmp_path, world):
+@pytest.mark.parametrize("world,one_launch", [(2, False), (3, False), (3, True)])
+def test_p2p_ranks_in_separate_processes_equal_one_slab(hip_lib, tmp_path, world, one_launch):
     import torch.multiprocessing as mp
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), one_launch), nprocs=world, join=True)
     s = patch_sim(*SHAPE, cpml_cells=8, nr_ts=STEPS)
     e = s.build(hip_lib)
     e.run(STEPS)
