@@ -181,6 +181,7 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   if (const char* v = getenv("FDTD_OCC_E")) c->occ_e = std::max(0, std::min(16, atoi(v)));
   if (const char* v = getenv("FDTD_NT")) p.nt = atoi(v) ? 1 : 0;                       // experiments
   if (const char* v = getenv("FDTD_OCC_WF")) c->occ_wf = std::max(0, std::min(16, atoi(v)));
+  if (getenv("FDTD_MUR_UNFUSED")) c->mur_fuse_post = false;   // experiments: the Mur post pass as a launch of its own
   if (const char* v = getenv("FDTD_WAVEFRONT")) c->wf_mode = atoi(v) ? 1 : 0;
   if (const char* v = getenv("FDTD_WF_LAG")) c->wf_lag = std::max(0, std::min(4096, atoi(v)));
   if (const char* v = getenv("FDTD_OCC_H")) c->occ_h = std::max(0, std::min(16, atoi(v)));
@@ -738,6 +739,10 @@ static int phase_E(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
     return FDTD_OK;
   };
   if (!split) { int r = wait_halo(); if (r) return r; }
+  // single slab with Mur faces and fused sources: the post pass rides in the update_E launch (E+post, apply, H+pre: three
+  // launches per timestep instead of four — on the reference's default 56x55x50 scene every launch is a ~4 us latency floor)
+  c->mur_post_in_E = fused && c->any_mur && !multi && c->d_mur != nullptr && c->mur_fuse_post &&
+                     c->d.nx >= 5 && c->d.ny >= 5 && c->d.nz >= 5;
   launch_update_E(c, split ? 1 : 0, nk, step, fused, true, s);
   c->kev0 = c->kev1 = nullptr;
   if (split) {
@@ -745,7 +750,8 @@ static int phase_E(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
     if (r) return r;
     launch_update_E(c, 0, 1, step, fused, false, s);
   }
-  launch_mur(c, 1, s);   // post + apply (no-ops without Mur faces)
+  if (!c->mur_post_in_E) launch_mur(c, 1, s);   // post + apply (no-ops without Mur faces)
+  c->mur_post_in_E = false;
   launch_mur(c, 2, s);
   if (!fused) launch_post(c, FDTD_KIND_V, step, true, s);
   launch_dft(c, FDTD_KIND_V, step, s);

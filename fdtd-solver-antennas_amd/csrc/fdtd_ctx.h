@@ -152,6 +152,8 @@ struct fdtd_ctx {
   MurFace mur[6] = {};
   bool any_mur = false;
   MurDev h_mur{}; MurDev* d_mur = nullptr;   // face table (built by fdtd_set_mur), host and device copy
+  bool mur_fuse_post = true;                 // allow it ($FDTD_MUR_UNFUSED clears)
+  bool mur_post_in_E = false;                // this launch of update_E runs the Mur post pass as well (set by phase_E)
   int64_t mur_pre_step = -1;                 // step whose Mur pre pass has already run (inside the previous update_H launch)
   // excitation
   float* sig = nullptr; int nsig = 0;

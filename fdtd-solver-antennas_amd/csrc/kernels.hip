@@ -35,12 +35,68 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // K1: E half-step
 // ------------------------------------------------------------------------------------------------
+// Mur "post" pass (mode 1 of k_mur: S <- S + coeff * V_inner with the freshly updated V) for the face points whose inner
+// point this thread has just computed — the thread owns cells i0..i0+3 of row j in plane k and holds the new Vx, Vy, Vz.
+// A face point is touched by exactly one thread, so the (single) update per point is that of k_mur, bit for bit.
+// Two phases: the S values are LOADED with the field loads at the top of the kernel (PHASE 0) and updated + stored at its end
+// (PHASE 1); loaded at the end they were a second, exposed memory round trip (update_E + post 8.7 us on the reference's
+// 56x55x50 scene: exactly the 4.9 + 4.0 us of the two separate launches).  Per axis a thread lies next to at most one face
+// (the host takes the separate launch for grids under 5 nodes along an axis).
+struct MurVals { float4 z0, z1, y0, y1; float x0, x1; };
+__device__ __forceinline__ void mur_ld4(float4& r, const float* S, const int n) {
+  r.x = S[0]; r.y = n > 1 ? S[1] : 0.f; r.z = n > 2 ? S[2] : 0.f; r.w = n > 3 ? S[3] : 0.f;
+}
+__device__ __forceinline__ void mur_st4(float* S, const float c, const float4& v, const float4& s, const int n) {
+  S[0] = __builtin_fmaf(c, v.x, s.x);
+  if (n > 1) S[1] = __builtin_fmaf(c, v.y, s.y);
+  if (n > 2) S[2] = __builtin_fmaf(c, v.z, s.z);
+  if (n > 3) S[3] = __builtin_fmaf(c, v.w, s.w);
+}
+template <int PHASE>
+__device__ __forceinline__ void mur_post_inline(const DevParams& p, const MurDev& m, const int k, const int j, const int i0, MurVals& mv,
+                                                const float4& vx, const float4& vy, const float4& vz) {
+  const int n = p.nx - i0;   // cells of the thread's group inside the grid
+#pragma unroll
+  for (int fi = 0; fi < 6; ++fi) {
+    const MurDevFace& f = m.f[fi];
+    if (!f.on) continue;
+    const int a = fi >> 1;
+    if (a == 2) {          // z faces: tangential x, y; s = j * nx + i (block-uniform test)
+      if (k != f.in) continue;
+      float* const S0 = f.st[0] + j * p.nx + i0;
+      float* const S1 = f.st[1] + j * p.nx + i0;
+      if (PHASE == 0) { mur_ld4(mv.z0, S0, n); mur_ld4(mv.z1, S1, n); }
+      else { mur_st4(S0, f.coeff, vx, mv.z0, n); mur_st4(S1, f.coeff, vy, mv.z1, n); }
+    } else if (a == 1) {   // y faces: comp[0] = z, comp[1] = x; s = k * nx + i
+      if (j != f.in) continue;
+      float* const S0 = f.st[0] + k * p.nx + i0;
+      float* const S1 = f.st[1] + k * p.nx + i0;
+      if (PHASE == 0) { mur_ld4(mv.y0, S0, n); mur_ld4(mv.y1, S1, n); }
+      else { mur_st4(S0, f.coeff, vz, mv.y0, n); mur_st4(S1, f.coeff, vx, mv.y1, n); }
+    } else {               // x faces: comp[0] = y, comp[1] = z; s = k * ny + j; one of the thread's four cells at most
+      const int e = f.in - i0;
+      if (e < 0 || e > 3) continue;
+      float* const S0 = f.st[0] + k * p.ny + j;
+      float* const S1 = f.st[1] + k * p.ny + j;
+      if (PHASE == 0) { mv.x0 = *S0; mv.x1 = *S1; }
+      else {   // four static cases: selecting the component with a computed index sends the vectors through scratch
+        if (e == 0) { *S0 = __builtin_fmaf(f.coeff, vy.x, mv.x0); *S1 = __builtin_fmaf(f.coeff, vz.x, mv.x1); }
+        if (e == 1) { *S0 = __builtin_fmaf(f.coeff, vy.y, mv.x0); *S1 = __builtin_fmaf(f.coeff, vz.y, mv.x1); }
+        if (e == 2) { *S0 = __builtin_fmaf(f.coeff, vy.z, mv.x0); *S1 = __builtin_fmaf(f.coeff, vz.z, mv.x1); }
+        if (e == 3) { *S0 = __builtin_fmaf(f.coeff, vy.w, mv.x0); *S1 = __builtin_fmaf(f.coeff, vz.w, mv.x1); }
+      }
+    }
+  }
+}
+
 // COEF: 0 raw arrays, 1 class byte per edge, 2 one packed class byte per cell
 // WF: the block is part of a one-launch-per-timestep wavefront (k_step below): V goes out write-through (sc1) and the block
 // publishes its flag when every wave's stores have been acknowledged.
-template <int COEF, bool PML, bool FUSE, bool P2P, bool WF>
+// MUR: the block also runs the Mur "post" pass (S += coeff * V_new on the plane next to each Mur face) for the points it owns.
+template <int COEF, bool PML, bool FUSE, bool P2P, bool WF, bool MUR = false>
 __device__ __forceinline__ void body_E(const DevParams& p, const int strip, const int k, const int pb, const long long step,
-                                       float2* const s_lut, float4* const s_psi, float* const s_xc, SrcStage& s_src, const unsigned wf_target) {
+                                       float2* const s_lut, float4* const s_psi, float* const s_xc, SrcStage& s_src, const unsigned wf_target,
+                                       const MurDev& mur = *static_cast<const MurDev*>(nullptr)) {
   // coefficient table -> LDS by LDS-DMA, issued FIRST: no staging registers (the kernel has none to spare), and since
   // vector-memory operations retire in order a counted wait below leaves the field loads behind it in flight.
   // Thread t moves entries 2t, 2t+1 (16 bytes; the destination of an LDS-DMA load is lane-linear, so the table lands
@@ -75,6 +131,8 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
   if (!dep_in) { iy_km = ldo4(I1 - p.plane, uo); ix_km = ldo4(I0 - p.plane, uo); }
   const float iz_im = ldo1(I2 - 1, uo), iy_im = ldo1(I1 - 1, uo);
   float4 vx = ldo4(p.V[0] - p.plane, uo), vy = ldo4(p.V[1] - p.plane, uo), vz = ldo4(p.V[2] - p.plane, uo);
+  MurVals mv;
+  if (MUR && valid) mur_post_inline<0>(p, mur, k, j, i0, mv, vx, vy, vz);   // the S values of the Mur post pass travel with the field loads
   // Soft sources inside this strip-plane (block-uniform range; almost always empty).  The range comes by an explicit SCALAR
   // load: left to the compiler this uniform load sits behind the LDS-DMA statements (asm, "memory"), cannot be proven
   // unclobbered and becomes a vector load + s_waitcnt vmcnt(0) in the middle of the load phase — every wave then waited for
@@ -180,6 +238,7 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
     else sto4s(p.nt, p.V[comp], (unsigned)off, v);
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (MUR) mur_post_inline<1>(p, mur, k, j, i0, mv, vx, vy, vz);
   if (P2P && k == 0 && p.mb_out_E != nullptr) {   // push the new Vx, Vy of the bottom plane into the lower rank's mailbox
     float* mb = p.mb_out_E + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
     st4_sys(mb, vx);
@@ -211,6 +270,23 @@ __global__ __launch_bounds__(FDTD_BLOCK, (PML || (COEF == 0 && P2P)) ? FDTD_E_MI
     k = k_begin + kk;
   }
   body_E<COEF, PML, FUSE, P2P, false>(p, strip, k, pb, step, s_lut, s_psi, s_xc, s_src, 0u);
+}
+
+// update_E of a single slab with Mur faces, sources fused: the "post" pass rides along (one launch less per timestep).
+template <int COEF, bool PML>
+__global__ __launch_bounds__(FDTD_BLOCK, 4) void k_update_E_mur(const DevParams p, const int k_begin, const FastDiv fd_ps,
+                                                                                const long long step, const int extra, const MurDev m) {
+  extern __shared__ float2 s_lut[];
+  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : FDTD_BLOCK / 2];
+  __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
+  __shared__ SrcStage s_src;
+  if (extra && blockIdx.x == gridDim.x - 1) {   // probe block: H-probes of the step just finished
+    probe_block(p, FDTD_KIND_I, step - 1, reinterpret_cast<double*>(s_psi));
+    return;
+  }
+  int strip, kk, pb;
+  decode_block_fd(fd_ps, p.fd_nbs, extra, 0, strip, kk, pb);
+  body_E<COEF, PML, true, false, false, true>(p, strip, k_begin + kk, pb, step, s_lut, s_psi, s_xc, s_src, 0u, m);
 }
 
 // Mur "pre" pass (mode 0 of k_mur) of one block: S = V_inner - coeff * V_boundary on the values BEFORE the next E update.
@@ -647,6 +723,10 @@ static void launch_E2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long st
     return;
   }
   const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
+  if (fused && c->mur_post_in_E) {
+    launch_main(c, k_update_E_mur<COEF, PML>, grid, pad, s, c->p, k_begin, fd_ps, step, extra, c->h_mur);
+    return;
+  }
   if (fused) launch_main(c, k_update_E<COEF, PML, true, false>, grid, pad, s, c->p, k_begin, fd_ps, step, extra, 0u);
   else launch_main(c, k_update_E<COEF, PML, false, false>, grid, pad, s, c->p, k_begin, fd_ps, step, 0, 0u);
 }
