@@ -74,9 +74,10 @@ enum {
      z-marching kernel on an LDS-DMA ring (round 2, git history).  All were bit-exact and all measured slower than the two
      passes (profiles/r01, profiles/r02/one_pass_*); none ships: selecting them is FDTD_E_UNSUPPORTED. */
   FDTD_FLAG_KERNEL_WAVEFRONT = 5, /* ONE launch per timestep: the E sweep runs a few planes ahead of the H sweep, coupled by per-block
-                                    flags, so that H reads what E just touched from the Infinity Cache instead of HBM.  Single slab,
-                                    no Mur faces (else FDTD_E_UNSUPPORTED).  AUTO picks it for grids beyond the Infinity Cache; DIRECT
-                                    never does.  Results are identical to the two-pass kernels bit for bit. */
+                                    flags, so that H reads what E just touched from the Infinity Cache instead of HBM.  Single slab, or
+                                    slabs on the p2p mailbox transport; no Mur faces (else FDTD_E_UNSUPPORTED).  AUTO picks it for
+                                    slabs whose fields exceed the Infinity Cache; DIRECT never does.  Results are identical to the
+                                    two-pass kernels bit for bit.  fdtd_profile.fused = 1: ms_update_e is the whole timestep's launch. */
   FDTD_FLAG_KERNEL_MASK   = 0xF,
   FDTD_FLAG_NO_GRAPH      = 0x10, /* reserved */
   FDTD_FLAG_OVERLAP_ON    = 0x20, /* multi-slab: split sweeps into interior + halo-dependent plane (the default) */
@@ -106,7 +107,7 @@ typedef struct fdtd_profile {
   int32_t launches_e;     /* launches averaged */
   int32_t launches_h;
   int32_t steps;
-  int32_t fused;          /* always 0 since ABI v2 (field kept for layout compatibility) */
+  int32_t fused;          /* 1: one launch per timestep (FDTD_FLAG_KERNEL_WAVEFRONT schedule): ms_update_e is that launch, ms_update_h = 0 */
   double ms_event_overhead; /* always 0 since ABI v2: the durations are the dispatches' own begin / end timestamps
                                (start / stop events carried by each launch), nothing is subtracted */
 } fdtd_profile;
