@@ -52,3 +52,13 @@ def test_create_without_gpu_reports_error():
     import pytest
     with pytest.raises(capi.FdtdError, match="no HIP device"):
         capi.Engine(lib, 8, 8, 8, 1e-12)
+
+
+def test_flag_constants_of_the_binding_match_the_header():
+    """The ctypes stub spells the kernel-schedule / transport flags as literals: they must be the header's values."""
+    import re
+    capi = pkg("_capi")
+    text = open(os.path.join(ROOT, "include", "fdtd_hip.h")).read()
+    enum = dict((m.group(1), int(m.group(2), 0)) for m in re.finditer(r"\b(FDTD_FLAG_\w+)\s*=\s*(0x[0-9A-Fa-f]+|\d+)", text))
+    for name in ("KERNEL_AUTO", "KERNEL_DIRECT", "KERNEL_WAVEFRONT", "NO_GRAPH", "OVERLAP_ON", "OVERLAP_OFF", "LOOPBACK"):
+        assert getattr(capi, "FLAG_" + name) == enum["FDTD_FLAG_" + name], name
