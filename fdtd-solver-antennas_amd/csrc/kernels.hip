@@ -96,7 +96,7 @@ __device__ __forceinline__ void mur_post_inline(const DevParams& p, const MurDev
 template <int COEF, bool PML, bool FUSE, bool P2P, bool WF, bool MUR = false>
 __device__ __forceinline__ void body_E(const DevParams& p, const int strip, const int k, const int pb, const long long step,
                                        float2* const s_lut, float4* const s_psi, float* const s_xc, SrcStage& s_src, const unsigned wf_target,
-                                       const MurDev& mur = *static_cast<const MurDev*>(nullptr)) {
+                                       const MurDev* const mur = nullptr) {
   // coefficient table -> LDS by LDS-DMA, issued FIRST: no staging registers (the kernel has none to spare), and since
   // vector-memory operations retire in order a counted wait below leaves the field loads behind it in flight.
   // Thread t moves entries 2t, 2t+1 (16 bytes; the destination of an LDS-DMA load is lane-linear, so the table lands
@@ -132,7 +132,7 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
   const float iz_im = ldo1(I2 - 1, uo), iy_im = ldo1(I1 - 1, uo);
   float4 vx = ldo4(p.V[0] - p.plane, uo), vy = ldo4(p.V[1] - p.plane, uo), vz = ldo4(p.V[2] - p.plane, uo);
   MurVals mv;
-  if (MUR && valid) mur_post_inline<0>(p, mur, k, j, i0, mv, vx, vy, vz);   // the S values of the Mur post pass travel with the field loads
+  if (MUR && valid) mur_post_inline<0>(p, *mur, k, j, i0, mv, vx, vy, vz);   // the S values of the Mur post pass travel with the field loads
   // Soft sources inside this strip-plane (block-uniform range; almost always empty).  The range comes by an explicit SCALAR
   // load: left to the compiler this uniform load sits behind the LDS-DMA statements (asm, "memory"), cannot be proven
   // unclobbered and becomes a vector load + s_waitcnt vmcnt(0) in the middle of the load phase — every wave then waited for
@@ -238,7 +238,7 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
     else sto4s(p.nt, p.V[comp], (unsigned)off, v);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (MUR) mur_post_inline<1>(p, mur, k, j, i0, mv, vx, vy, vz);
+  if (MUR) mur_post_inline<1>(p, *mur, k, j, i0, mv, vx, vy, vz);
   if (P2P && k == 0 && p.mb_out_E != nullptr) {   // push the new Vx, Vy of the bottom plane into the lower rank's mailbox
     float* mb = p.mb_out_E + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
     st4_sys(mb, vx);
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, 4) void k_update_E_mur(const DevParams 
   }
   int strip, kk, pb;
   decode_block_fd(fd_ps, p.fd_nbs, extra, 0, strip, kk, pb);
-  body_E<COEF, PML, true, false, false, true>(p, strip, k_begin + kk, pb, step, s_lut, s_psi, s_xc, s_src, 0u, m);
+  body_E<COEF, PML, true, false, false, true>(p, strip, k_begin + kk, pb, step, s_lut, s_psi, s_xc, s_src, 0u, &m);
 }
 
 // Mur "pre" pass (mode 0 of k_mur) of one block: S = V_inner - coeff * V_boundary on the values BEFORE the next E update.
