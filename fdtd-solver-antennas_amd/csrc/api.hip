@@ -1042,14 +1042,14 @@ int fdtd_halo_put(fdtd_ctx* c, int which, const float* buf) {
 
 // ---- in-process transport: several slabs driven by one host thread ---------------------------------------
 // ---- P2P mailbox transport ----------------------------------------------------------------------------------
-// Mailbox of a context: [E: 2 parities x 2 comps x plane][H: the same] floats, then 64 control words:
-// [0] E halos received, [1] H halos received, [2],[3] arrival counters, [4] error word, [8..] self-test slots.
+// Mailbox of a context: [E: 2 parities x 2 comps x 2*plane][H: the same] words (8-byte granules {value, tag}), then 64
+// control words: [4] error word (the rest is unused since the granule protocol: no flags, no arrival counters).
 __global__ void k_wallclock(unsigned long long* out) { *out = (unsigned long long)wall_clock64(); }
 
 struct P2pBlob { hipIpcMemHandle_t h; uint64_t bytes; uint64_t raw; int32_t pid, device, nx, ny; };
 static_assert(sizeof(P2pBlob) <= 128, "blob must fit the 128-byte exchange buffer");
 
-static size_t p2p_floats(const fdtd_ctx* c) { return (size_t)8 * c->plane; }
+static size_t p2p_floats(const fdtd_ctx* c) { return (size_t)16 * c->plane; }
 
 // The mailbox is only ever touched with system-scope (write-through / cache-bypassing) accesses — also when it is zeroed,
 // so that no plain fill leaves copies of its lines in some XCD's L2 for a later mailbox load to find.
@@ -1061,9 +1061,9 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_zero(float* mbox, const size
 }
 // zero the halo planes (and, with `ctl`, the 64 control words) of this context's own mailbox, on its stream
 static void p2p_zero(fdtd_ctx* c, bool ctl) {
-  const size_t n4 = (size_t)2 * c->plane;   // 8 planes of floats = 2 * plane float4 groups
+  const size_t n4 = p2p_floats(c) / 4;      // 16-byte groups of the halo part
   hipLaunchKernelGGL(k_p2p_zero, dim3((unsigned)((n4 + FDTD_BLOCK - 1) / FDTD_BLOCK)), dim3(FDTD_BLOCK), 0, c->stream,
-                     (float*)c->mbox, n4, ctl ? (unsigned*)((float*)c->mbox + (size_t)8 * c->plane) : nullptr, 64);
+                     (float*)c->mbox, n4, ctl ? (unsigned*)((float*)c->mbox + p2p_floats(c)) : nullptr, 64);
 }
 
 static int p2p_alloc(fdtd_ctx* c) {
@@ -1088,7 +1088,7 @@ static int p2p_alloc(fdtd_ctx* c) {
 
 static void p2p_views(const fdtd_ctx* c, void* base, float** in_E, float** in_H, unsigned** ctl) {
   float* f = (float*)base;
-  *in_E = f; *in_H = f + 4 * (size_t)c->plane; *ctl = (unsigned*)(f + p2p_floats(c));
+  *in_E = f; *in_H = f + 8 * (size_t)c->plane; *ctl = (unsigned*)(f + p2p_floats(c));
 }
 
 int fdtd_p2p_export(fdtd_ctx* c, void* out128) {
@@ -1154,16 +1154,10 @@ int fdtd_p2p_attach(fdtd_ctx* c, const void* lower128, const void* upper128) {
   DevParams& p = c->p;
   p.mb_in_E = upper128 ? in_E : nullptr;
   p.mb_in_H = lower128 ? in_H : nullptr;
-  p.fl_in = ctl; p.p2p_cnt = ctl + 2; p.p2p_err = (int*)(ctl + 4);
-  p.mb_out_E = nullptr; p.mb_out_H = nullptr; p.fl_out_E = nullptr; p.fl_out_H = nullptr;
-  if (c->peer_lo) { float *e, *h; unsigned* f; p2p_views(c, c->peer_lo, &e, &h, &f); p.mb_out_E = e; p.fl_out_E = f + 0; }
-  if (c->peer_hi) { float *e, *h; unsigned* f; p2p_views(c, c->peer_hi, &e, &h, &f); p.mb_out_H = h; p.fl_out_H = f + 1; }
-  int waves = 0;   // waves with a valid thread among the blocks of one plane
-  for (int s = 0; s < p.nstrips; ++s) {
-    const int rows = std::min(p.tys, p.ny - s * p.tys);
-    waves += (rows * p.P4 + 63) / 64;
-  }
-  p.p2p_waves = waves;
+  p.p2p_err = (int*)(ctl + 4);
+  p.mb_out_E = nullptr; p.mb_out_H = nullptr;
+  if (c->peer_lo) { float *e, *h; unsigned* f; p2p_views(c, c->peer_lo, &e, &h, &f); p.mb_out_E = e; }
+  if (c->peer_hi) { float *e, *h; unsigned* f; p2p_views(c, c->peer_hi, &e, &h, &f); p.mb_out_H = h; }
   // wall_clock64() tick rate: measured against the host clock (the attribute is not reliable on every part)
   {
     unsigned long long* d_t = nullptr;
@@ -1183,16 +1177,17 @@ int fdtd_p2p_attach(fdtd_ctx* c, const void* lower128, const void* upper128) {
     if (!(hz > 1e6 && hz < 1e11)) hz = 1e8;
     p.p2p_limit = (unsigned long long)(hz * 10.0);
   }
+  p.p2p_dep_first = getenv("FDTD_P2P_DEP_LAST") ? 0 : 1;
   p.p2p = 1;
   return FDTD_OK;
 }
 
 // Self-test over the attached mailboxes, THROUGH THE DATA PATH of the update kernels: every rank fills both parities of
-// both halo planes in its neighbours' mailboxes with a token-derived pattern using the same 16-byte write-through
-// stores (st4_sys), drains them (vmcnt) and publishes the token; then it waits (bounded, 10 s) for its neighbours'
-// tokens and reads its own mailbox back with the same cache-bypassing 16-byte loads (ld4_sys), comparing every word.
-// A link on which flags cross but payload stores lag, tear or vanish fails here instead of corrupting halos.
-// Two launches (post, then wait + verify), so that a grid larger than the chip can never wait on its own blocks.
+// both halo components in its neighbours' mailboxes with a token-derived pattern through the very function the update
+// kernels push with (mb_push: 16-byte write-through stores of {value, tag} granules, tag = token); then every thread polls
+// ITS groups of its own mailbox with the kernels' loads until all tags are the token (bounded) and compares every value.
+// A link on which stores tear below 8 bytes, vanish or land in the wrong place fails here instead of corrupting halos.
+// Two launches (post, then poll + verify), so that a grid larger than the chip can never wait on its own blocks.
 // Call on all ranks at about the same time.
 __device__ __forceinline__ float4 p2p_pattern(const unsigned token, const unsigned dir, const unsigned slot, const unsigned t) {
   const unsigned h = (token * 2654435761u) ^ (dir * 0x9E3779B9u) ^ (slot * 0x85EBCA6Bu) ^ (t * 0xC2B2AE35u);
@@ -1204,64 +1199,35 @@ __device__ __forceinline__ float4 p2p_pattern(const unsigned token, const unsign
 
 __global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_selftest_post(const DevParams p, const unsigned token) {
   const unsigned t = blockIdx.x * FDTD_BLOCK + threadIdx.x, n4 = (unsigned)p.plane / 4u;
-  if (t < n4) {
-    for (unsigned slot = 0; slot < 4u; ++slot) {   // slot = parity * 2 + component
-      if (p.mb_out_E) st4_sys(p.mb_out_E + (size_t)slot * p.plane + 4u * t, p2p_pattern(token, 0u, slot, t));
-      if (p.mb_out_H) st4_sys(p.mb_out_H + (size_t)slot * p.plane + 4u * t, p2p_pattern(token, 1u, slot, t));
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores ...
-  __syncthreads();                                    // ... before ONE lane signals for the whole workgroup
-  if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(p.p2p_cnt + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (old == gridDim.x - 1u) {
-      __hip_atomic_store(p.p2p_cnt + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (p.fl_out_E) __hip_atomic_store(p.fl_out_E + 8 + 1, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);        // lower's "from upper" slot
-      if (p.fl_out_H) __hip_atomic_store((p.fl_out_H - 1) + 8 + 0, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // upper's "from lower" slot
-    }
+  if (t >= n4) return;
+  for (unsigned slot = 0; slot < 4u; ++slot) {   // slot = parity * 2 + component
+    if (p.mb_out_E) mb_push(p.mb_out_E + slot * mb_slot_words(p), 4u * t, token, p2p_pattern(token, 0u, slot, t));
+    if (p.mb_out_H) mb_push(p.mb_out_H + slot * mb_slot_words(p), 4u * t, token, p2p_pattern(token, 1u, slot, t));
   }
 }
 
-// result[0]: blocks that timed out waiting for a token; result[1]: float4 groups that read back wrong;
+// result[0]: waves that gave up waiting for the neighbour's granules; result[1]: 16-byte groups that read back wrong;
 // result[2]: index (slot * n4 + t, +2^30 for the H mailbox) of one wrong group, result[3]: its first word as read
-__global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_selftest_verify(const DevParams p, const unsigned token, unsigned* result) {
-  __shared__ int s_ok;
-  if (threadIdx.x == 0) {
-    const unsigned long long t0 = wall_clock64();
-    int ok = 1;
-    for (int side = 0; side < 2 && ok; ++side) {
-      const bool have = side == 0 ? p.mb_in_H != nullptr : p.mb_in_E != nullptr;   // lower / upper neighbour exists
-      if (!have) continue;
-      while (__hip_atomic_load(p.fl_in + 8 + side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != token) {
-        __builtin_amdgcn_s_sleep(16);
-        if ((unsigned long long)wall_clock64() - t0 > p.p2p_limit) { ok = 0; break; }
-      }
-    }
-    s_ok = ok;
-    if (!ok) atomicAdd(result + 0, 1u);
-  }
-  __syncthreads();
-  if (!s_ok) return;
-  const unsigned t = blockIdx.x * FDTD_BLOCK + threadIdx.x, n4 = (unsigned)p.plane / 4u;
-  if (t >= n4) return;
+__global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_selftest_verify(const DevParams p, const unsigned token, unsigned* result, int* err) {
+  const unsigned t0 = blockIdx.x * FDTD_BLOCK + threadIdx.x, n4 = (unsigned)p.plane / 4u;
+  const unsigned t = t0 < n4 ? t0 : 0u;   // lanes beyond the plane pull group 0 (mb_pull2 needs whole waves)
   unsigned bad = 0;
-  for (unsigned slot = 0; slot < 4u; ++slot) {
-    if (p.mb_in_E) {   // written by the upper neighbour as ITS E-down halo (dir 0)
-      const float4 g = ld4_sys(p.mb_in_E + (size_t)slot * p.plane + 4u * t), w = p2p_pattern(token, 0u, slot, t);
-      const unsigned b = (__float_as_uint(g.x) != __float_as_uint(w.x)) | (__float_as_uint(g.y) != __float_as_uint(w.y)) |
-                         (__float_as_uint(g.z) != __float_as_uint(w.z)) | (__float_as_uint(g.w) != __float_as_uint(w.w));
-      if (b) { result[2] = slot * n4 + t; result[3] = __float_as_uint(g.x); }
-      bad += b;
-    }
-    if (p.mb_in_H) {   // written by the lower neighbour as ITS H-up halo (dir 1)
-      const float4 g = ld4_sys(p.mb_in_H + (size_t)slot * p.plane + 4u * t), w = p2p_pattern(token, 1u, slot, t);
-      const unsigned b = (__float_as_uint(g.x) != __float_as_uint(w.x)) | (__float_as_uint(g.y) != __float_as_uint(w.y)) |
-                         (__float_as_uint(g.z) != __float_as_uint(w.z)) | (__float_as_uint(g.w) != __float_as_uint(w.w));
-      if (b) { result[2] = (1u << 30) + slot * n4 + t; result[3] = __float_as_uint(g.x); }
-      bad += b;
+  for (unsigned pair = 0; pair < 2u; ++pair) {   // the two components of one parity at a time, as the kernels pull them
+    for (int side = 0; side < 2; ++side) {
+      const float* in = side == 0 ? p.mb_in_E : p.mb_in_H;   // written by the upper neighbour as ITS E-down halo (dir 0) / by the lower as ITS H-up halo (dir 1)
+      if (!in) continue;
+      float4 ga, gb;
+      mb_pull2(in + (2u * pair) * mb_slot_words(p), in + (2u * pair + 1u) * mb_slot_words(p), 4u * t, token, ga, gb, err, p.p2p_limit);
+      for (unsigned q = 0; q < 2u; ++q) {
+        const float4 g = q ? gb : ga, w = p2p_pattern(token, (unsigned)side, 2u * pair + q, t);
+        const unsigned b = (__float_as_uint(g.x) != __float_as_uint(w.x)) | (__float_as_uint(g.y) != __float_as_uint(w.y)) |
+                           (__float_as_uint(g.z) != __float_as_uint(w.z)) | (__float_as_uint(g.w) != __float_as_uint(w.w));
+        if (b && t0 < n4) { result[2] = ((unsigned)side << 30) + (2u * pair + q) * n4 + t; result[3] = __float_as_uint(g.x); bad += b; }
+      }
     }
   }
   if (bad) atomicAdd(result + 1, bad);
+  if (threadIdx.x == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicAdd(result + 0, 1u);
 }
 
 int fdtd_p2p_selftest(fdtd_ctx* c, unsigned token) {
@@ -1271,27 +1237,24 @@ int fdtd_p2p_selftest(fdtd_ctx* c, unsigned token) {
   if (token == 0u) return fdtd_fail(c, FDTD_E_ARG, "p2p self-test token must be non-zero");
   HIPCK(c, hipSetDevice(c->d.device));
   unsigned* d_res = nullptr;
-  HIPCK(c, hipMalloc(&d_res, 4 * sizeof(unsigned)));
-  HIPCK(c, hipMemsetAsync(d_res, 0, 4 * sizeof(unsigned), c->stream));   // the context's stream is non-blocking: keep everything on it
+  HIPCK(c, hipMalloc(&d_res, 6 * sizeof(unsigned)));
+  HIPCK(c, hipMemsetAsync(d_res, 0, 6 * sizeof(unsigned), c->stream));   // the context's stream is non-blocking: keep everything on it
+  int* d_err = reinterpret_cast<int*>(d_res + 4);                          // the self-test's own error word (a failed test must not poison the run's)
   const unsigned nb = (unsigned)((c->plane / 4 + FDTD_BLOCK - 1) / FDTD_BLOCK);
   hipLaunchKernelGGL(k_p2p_selftest_post, dim3(nb), dim3(FDTD_BLOCK), 0, c->stream, c->p, token);
-  hipLaunchKernelGGL(k_p2p_selftest_verify, dim3(nb), dim3(FDTD_BLOCK), 0, c->stream, c->p, token, d_res);
+  hipLaunchKernelGGL(k_p2p_selftest_verify, dim3(nb), dim3(FDTD_BLOCK), 0, c->stream, c->p, token, d_res, d_err);
   unsigned res[4] = {0, 0, 0, 0};
   hipError_t e = hipMemcpyAsync(res, d_res, sizeof(res), hipMemcpyDeviceToHost, c->stream);
-  // all neighbours' pattern stores into THIS mailbox were acknowledged before their tokens arrived: restore the zeros
-  // the first timestep expects (the halo of "step -1" is the zero initial field), leave flags and counters alone
+  // every granule of the neighbours' patterns has been seen in THIS mailbox (or the test has failed): restore the zeros
+  // the first timestep expects (the halo of "step -1" is the zero initial field with tag 0)
   if (e == hipSuccess) p2p_zero(c, false);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   hipFree(d_res);
   HIPCK(c, e);
-  if (res[0]) {
-    unsigned slots[2] = {0, 0};
-    hipMemcpy(slots, c->p.fl_in + 8, sizeof(slots), hipMemcpyDeviceToHost);
-    return fdtd_fail(c, FDTD_E_DEVICE, "p2p self-test: no token from a neighbour within the time limit (expected %#x; mailbox now holds from-lower %#x, from-upper %#x)",
-                     token, slots[0], slots[1]);
-  }
+  if (res[0])
+    return fdtd_fail(c, FDTD_E_DEVICE, "p2p self-test: a neighbour's halo granules did not arrive within the time limit (expected tag %#x; %u block(s) gave up)", token, res[0]);
   if (res[1])
-    return fdtd_fail(c, FDTD_E_DEVICE, "p2p self-test: %u of %u 16-byte halo groups read back wrong although the neighbour's token arrived (e.g. group %u of the %s mailbox reads %#x; %s device memory): payload stores do not reach this mailbox intact and in order",
+    return fdtd_fail(c, FDTD_E_DEVICE, "p2p self-test: %u of %u 16-byte halo groups read back wrong although their tags arrived (e.g. group %u of the %s mailbox reads %#x; %s device memory): payload stores do not reach this mailbox intact",
                      res[1], (unsigned)(c->plane / 4) * 4u * ((c->p.mb_in_E ? 1u : 0u) + (c->p.mb_in_H ? 1u : 0u)),
                      res[2] & ((1u << 30) - 1u), (res[2] >> 30) ? "H" : "E", res[3], c->mbox_fine ? "fine-grained" : "coarse-grained");
   return FDTD_OK;
@@ -1306,7 +1269,7 @@ int fdtd_p2p_detach(fdtd_ctx* c) {
   if (c->peer_hi && c->peer_hi_ipc) hipIpcCloseMemHandle(c->peer_hi);
   c->peer_lo = c->peer_hi = nullptr; c->peer_lo_ipc = c->peer_hi_ipc = false;
   DevParams& p = c->p;
-  p.p2p = 0; p.mb_in_E = p.mb_in_H = p.mb_out_E = p.mb_out_H = nullptr; p.fl_out_E = p.fl_out_H = nullptr;
+  p.p2p = 0; p.mb_in_E = p.mb_in_H = p.mb_out_E = p.mb_out_H = nullptr;
   if (c->mbox) { p2p_zero(c, true); HIPCK(c, hipStreamSynchronize(c->stream)); }
   return FDTD_OK;
 }

@@ -81,15 +81,13 @@ struct DevParams {
   FastDiv fd_nbs, fd_P4;     // dividers for the block / thread decode
   int sweep_rev;             // 1: update_H walks the blocks backwards (cache-friendly alternation with update_E)
   // P2P mailbox halo transport (in-kernel pushes over xGMI / peer mappings; no streams, events or RCCL in the step loop).
-  // Mailbox layout (one allocation per context, zero at start): [E: 2 parities][2 comps][plane] floats, then the same
-  // for H, then flags.  mb_in_*: my own mailbox; mb_out_*: the neighbour's (peer pointer), null without that neighbour.
+  // Mailbox layout (one allocation per context, zero at start): [E: 2 parities][2 comps][2 * plane] words — 8-byte granules
+  // {value, tag} — then the same for H, then 64 control words.  mb_in_*: my own mailbox; mb_out_*: the neighbour's (peer
+  // pointer), null without that neighbour.
   int p2p;                   // 1: the update kernels run the mailbox protocol
-  int p2p_waves;             // waves with at least one valid thread in one plane of blocks (arrival count of a push)
+  int p2p_dep_first;         // 1: the halo plane's blocks come first in dispatch order ($FDTD_P2P_DEP_LAST clears)
   float* mb_in_E; float* mb_in_H;     // V x,y of the upper neighbour's plane 0 / I x,y of the lower neighbour's top plane
   float* mb_out_E; float* mb_out_H;   // lower neighbour's mb_in_E / upper neighbour's mb_in_H
-  unsigned* fl_in;           // [0]: E halos received (= step + 1 of the newest), [1]: H halos received
-  unsigned* fl_out_E; unsigned* fl_out_H;   // &lower->fl_in[0], &upper->fl_in[1]
-  unsigned* p2p_cnt;         // local arrival counters [2]
   int* p2p_err;              // set when a halo wait timed out
   unsigned long long p2p_limit;   // wall-clock ticks a halo wait may last (10 s)
   // one launch per timestep (k_step): per-block completion flags of the E blocks [nk][nstrips][nbs], error word, wait limit

@@ -67,14 +67,17 @@ __device__ __forceinline__ void decode_block_fd(const FastDiv& fd_ps, const Fast
   strip = (int)s; kk = (int)k; pb = (int)(rem - k * fd_nbs.d);
 }
 // ---- P2P mailbox protocol -------------------------------------------------------------------------------------------
-// Mailbox words are only ever touched with system-scope (sc0 sc1) loads and stores, which go past this XCD's L2 to
-// memory / the fabric.  That is what lets the protocol do WITHOUT system-scope fences: a release or acquire fence
-// at system scope writes back or invalidates the whole L2 (measured: 300 us per step when every wave of the halo
-// plane issues one); here a wave only waits for its own write-through stores to be acknowledged (vmcnt) before it
-// counts itself in, and the flag is published by the wave that completes the count.
-// 128-bit accesses with the system-coherence bits (sc0 sc1) set: one fabric request per lane instead of four 4-byte
-// ones (over xGMI every request is a packet).  The compiler has no builtin for a 16-byte system-scope access, so
-// the two instructions are spelled out; the load waits for its own data (nothing else is in flight at that point).
+// A halo value travels as an 8-byte GRANULE {value, tag}: tag = number of the timestep whose half-step produced it (+1), in
+// the same naturally aligned 8 bytes as the value, so whoever sees the tag sees the value.  No flag, no arrival counter, no
+// wait for store acknowledgements on the producer; ONE round trip on the consumer (it loads the granules together with its
+// field loads and looks at the tags; only a late neighbour makes it load again).  The earlier protocol — payload stores,
+// vmcnt(0), wave counter, step flag; flag poll, then payload loads — cost 13 us per timestep on a thin slab (two more
+// dependent round trips in each kernel's halo plane: profiles/r02/thin_slab_p2p_protocol.txt).
+// A thread's float4 goes out as two 16-byte stores {x, t, y, t}, {z, t, w, t} (a 16-byte store may tear into its 8-byte
+// halves: each half is a granule of its own).  Mailbox words are only ever touched with system-scope (sc0 sc1) accesses,
+// which go past this XCD's L2 to memory / the fabric (the mailbox is fine-grained memory: another GPU writes it while this
+// one reads it).  Slots alternate with the parity of the step, so a value is overwritten two steps later — by then the
+// writer has consumed the reader's own halo of the step in between, which the reader produced after reading this one.
 typedef float v4f_sys __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld4_sys(const float* q) {
   v4f_sys r;
@@ -83,57 +86,64 @@ __device__ __forceinline__ float4 ld4_sys(const float* q) {
 }
 // The s_nop is part of the instruction's contract here: a vector-memory store of more than 64 bits reads its data
 // registers AFTER issue, and a VALU write to them in the next wait states corrupts what the later lanes store (hipcc pads
-// its own stores; it cannot see into an asm statement).  Found by the data-path self-test of the mailbox transport: the
-// last 64 bytes of every 256 of one plane arrived with a compiler temporary (0 / 1) in their first word.
-// two of them with ONE wait (the halo-dependent plane reads two components): both round trips overlap
-__device__ __forceinline__ void ld4x2_sys(const float* qa, const float* qb, float4& a, float4& b) {
-  v4f_sys ra, rb;
-  asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-               : "=&v"(ra), "=&v"(rb) : "v"(qa), "v"(qb) : "memory");
-  a = make_float4(ra.x, ra.y, ra.z, ra.w);
-  b = make_float4(rb.x, rb.y, rb.z, rb.w);
-}
+// its own stores; it cannot see into an asm statement).  Found by the data-path self-test of the mailbox transport.
 __device__ __forceinline__ void st4_sys(float* q, const float4& v) {
   const v4f_sys t = {v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(q), "v"(t) : "memory");
 }
-// One lane per wave polls the flag until it reaches `need` (bounded: `limit` ticks of the wall clock = 10 s, then the
-// error word is set and the wave goes on with whatever the mailbox holds; once the error word is set no wait spins).  The mailbox loads that follow are issued after
-// the loop in program order and bypass the caches, so a workgroup-scope fence (no cache maintenance) is enough.
-__device__ __forceinline__ void p2p_wait(const unsigned* flag, const unsigned need, int* err, const unsigned long long limit) {
-  const unsigned long long m = __ballot(1);
-  if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
-      __builtin_amdgcn_s_sleep(8);
-      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-      if ((unsigned long long)wall_clock64() - t0 > limit) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+// words of one (parity, component) slot: 2 per cell
+__device__ __forceinline__ size_t mb_slot_words(const DevParams& p) { return (size_t)2 * p.plane; }
+// push the four values of cell group `o` (element offset inside the plane, a multiple of 4) into slot `slot`
+__device__ __forceinline__ void mb_push(float* slot, const unsigned o, const unsigned tag, const float4& v) {
+  float* q = slot + 2u * o;
+  const float t = __uint_as_float(tag);
+  st4_sys(q, make_float4(v.x, t, v.y, t));
+  st4_sys(q + 4, make_float4(v.z, t, v.w, t));
 }
-// After a wave has stored its part of a halo into the neighbour's mailbox (st4_sys): wait for the acknowledgement of
-// those stores, count the wave; the wave that completes the plane publishes flag = value to the neighbour.
-__device__ __forceinline__ void p2p_arrive(unsigned* cnt, const unsigned total, unsigned* flag, const unsigned value) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's write-through mailbox stores are acknowledged
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  const unsigned long long m = __ballot(1);
-  if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
-    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (old == total - 1u) {
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+// pull the two halo components of cell group `o`: load both groups' granules, accept when all eight tags are `tag`; a wave
+// whose neighbour is late loads again (bounded: `limit` ticks of the wall clock, then the error word — never a hang; once
+// the error word is set nobody spins).  Every lane of the wave takes part (lanes beyond the strip pull group 0).
+__device__ __forceinline__ void mb_pull2(const float* slot_a, const float* slot_b, const unsigned o, const unsigned tag,
+                                         float4& a, float4& b, int* err, const unsigned long long limit) {
+  const float* qa = slot_a + 2u * o;
+  const float* qb = slot_b + 2u * o;
+  v4f_sys a0, a1, b0, b1;
+  unsigned long long t0 = 0ull;
+  for (int round = 0;; ++round) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off sc0 sc1\n\tglobal_load_dwordx4 %3, %5, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(qa), "v"(qb) : "memory");
+    const bool ok = __float_as_uint(a0.y) == tag && __float_as_uint(a0.w) == tag && __float_as_uint(a1.y) == tag && __float_as_uint(a1.w) == tag &&
+                    __float_as_uint(b0.y) == tag && __float_as_uint(b0.w) == tag && __float_as_uint(b1.y) == tag && __float_as_uint(b1.w) == tag;
+    if (__ballot(!ok) == 0ull) break;
+    if (round == 0) t0 = wall_clock64();
+    __builtin_amdgcn_s_sleep(4);
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    if ((unsigned long long)wall_clock64() - t0 > limit) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
   }
+  a = make_float4(a0.x, a0.z, a1.x, a1.z);
+  b = make_float4(b0.x, b0.z, b1.x, b1.z);
 }
-// Block decode of the P2P launches: all planes but the halo-dependent one first (strip-major as usual), the
-// dependent plane's blocks last in dispatch order, where they wait for the neighbour without holding up the rest.
-// dep_plane: 0 for update_E (then the main part covers planes 1..), nk-1 for update_H (main part planes 0..nk-2).
+// Block decode of the P2P launches.  dep_plane: 0 for update_E (the main part covers planes 1..), nk-1 for update_H (main
+// part planes 0..nk-2).  dep_first: the halo plane's blocks are the FIRST blocks in dispatch order — its pull from and push to
+// the neighbour's mailbox (fine-grained memory: a round trip of several microseconds) then run beside the other planes
+// instead of at the kernel's tail; a neighbour that is late makes these blocks load again while the rest proceeds.  With
+// dep_first = 0 they are the last ones (what the flag protocol of round 1 needed, when a wait could last a kernel).
 __device__ __forceinline__ void decode_block_p2p(const FastDiv& fd_ps, const FastDiv& fd_nbs, int extra, unsigned nb_main, int dep_plane,
-                                                 int main_first, int& strip, int& k, int& pb) {
+                                                 int main_first, int dep_first, int& strip, int& k, int& pb) {
   const unsigned nb = gridDim.x - (unsigned)extra, b = blockIdx.x;
-  const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
-  const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  unsigned v;
+  if (dep_first) {
+    const unsigned nb_dep = nb - nb_main;
+    if (b < nb_dep) v = nb_main + b;
+    else {
+      const unsigned bb = b - nb_dep, q = nb_main >> 3, r = nb_main & 7u, xcd = bb & 7u, pos = bb >> 3;
+      v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    }
+  } else {
+    const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
   if (v < nb_main) {
     const unsigned s = fd_div(v, fd_ps);
     const unsigned rem = v - s * fd_ps.d;

@@ -144,10 +144,9 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
   }
   if (PML && FDTD_PSI_STAGE)   // psi of the x / z layers: LDS-DMA right behind the field loads (kernel_common.hpp)
     psi_stage_issue(p, p.psiE, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
-  if (dep_in) {   // H halo of step-1 (flag value = steps delivered); parity of the step that produced it
-    p2p_wait(p.fl_in + 1, (unsigned)step, p.p2p_err, p.p2p_limit);
-    const float* mb = p.mb_in_H + (size_t)((step + 1) & 1) * 2 * p.plane + (j * p.P + i0);
-    ld4x2_sys(mb, mb + p.plane, ix_km, iy_km);
+  if (dep_in) {   // H halo of step-1 (tag = step: the zero initial field for step 0); slot of the parity of the step that produced it
+    const float* mb = p.mb_in_H + (size_t)((step + 1) & 1) * 2 * mb_slot_words(p);
+    mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step, ix_km, iy_km, p.p2p_err, p.p2p_limit);
   }
 
   // component x: d1 along y (of Iz), d2 along z (of Iy); y: d1 along z (Ix), d2 along x (Iz);
@@ -240,10 +239,9 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
   }
   if (MUR) mur_post_inline<1>(p, *mur, k, j, i0, mv, vx, vy, vz);
   if (P2P && k == 0 && p.mb_out_E != nullptr) {   // push the new Vx, Vy of the bottom plane into the lower rank's mailbox
-    float* mb = p.mb_out_E + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
-    st4_sys(mb, vx);
-    st4_sys(mb + p.plane, vy);
-    p2p_arrive(p.p2p_cnt + 0, (unsigned)p.p2p_waves, p.fl_out_E, (unsigned)step + 1u);
+    float* mb = p.mb_out_E + (size_t)(step & 1) * 2 * mb_slot_words(p);
+    mb_push(mb, (unsigned)(j * p.P + i0), (unsigned)step + 1u, vx);
+    mb_push(mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u, vy);
   }
   }   // valid
   if (WF) wf_publish(p, p.wf_flags, k, strip, pb, wf_target);
@@ -264,7 +262,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, (PML || (COEF == 0 && P2P)) ? FDTD_E_MI
   }
   int strip, kk, pb, k;
   if (P2P) {   // all planes in one launch, the halo-dependent bottom plane last
-    decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, 0, 1, strip, k, pb);
+    decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, 0, 1, p.p2p_dep_first, strip, k, pb);
   } else {
     decode_block_fd(fd_ps, p.fd_nbs, extra, 0, strip, kk, pb);
     k = k_begin + kk;
@@ -354,10 +352,9 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
     if (!dep_in) { vy_kp = ldb4_dev(b1, bo, (unsigned)p.plane << 2); vx_kp = ldb4_dev(b0, bo, (unsigned)p.plane << 2); }
     vz_ip = ldb1_dev(b2, bo, 16u); vy_ip = ldb1_dev(b1, bo, 16u);
   }
-  if (dep_in) {   // E halo of this step
-    p2p_wait(p.fl_in + 0, (unsigned)step + 1u, p.p2p_err, p.p2p_limit);
-    const float* mb = p.mb_in_E + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
-    ld4x2_sys(mb, mb + p.plane, vx_kp, vy_kp);
+  if (dep_in) {   // E halo of this step (tag = step + 1)
+    const float* mb = p.mb_in_E + (size_t)(step & 1) * 2 * mb_slot_words(p);
+    mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u, vx_kp, vy_kp, p.p2p_err, p.p2p_limit);
   }
 
   float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);
@@ -423,10 +420,9 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
   if (pub) { sto4_dev(p.I[0], uo, ix); sto4_dev(p.I[1], uo, iy); sto4_dev(p.I[2], uo, iz); }
   else { sto4s(p.nt, p.I[0], uo, ix); sto4s(p.nt, p.I[1], uo, iy); sto4s(p.nt, p.I[2], uo, iz); }
   if (P2P && k == p.nk - 1 && p.mb_out_H != nullptr) {   // push the new Ix, Iy of the top plane into the upper rank's mailbox
-    float* mb = p.mb_out_H + (size_t)(step & 1) * 2 * p.plane + (j * p.P + i0);
-    st4_sys(mb, ix);
-    st4_sys(mb + p.plane, iy);
-    p2p_arrive(p.p2p_cnt + 1, (unsigned)p.p2p_waves, p.fl_out_H, (unsigned)step + 1u);
+    float* mb = p.mb_out_H + (size_t)(step & 1) * 2 * mb_slot_words(p);
+    mb_push(mb, (unsigned)(j * p.P + i0), (unsigned)step + 1u, ix);
+    mb_push(mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u, iy);
   }
   }   // valid
   if (pub) wf_publish(p, p.wf_flagsH, k, strip, pb, wf_target);
@@ -447,7 +443,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
   }
   int strip, kk, pb, k;
   if (P2P) {   // all planes in one launch, the halo-dependent top plane last
-    decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, p.nk - 1, 0, strip, k, pb);
+    decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, p.nk - 1, 0, p.p2p_dep_first, strip, k, pb);
   } else {
     decode_block_fd(fd_ps, p.fd_nbs, extra, p.sweep_rev, strip, kk, pb);
     k = k_begin + kk;
@@ -472,7 +468,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
 // polling wave reads the flags with sc1 loads, the block meets, and EVERY load of V is an sc1 load to registers.
 // ------------------------------------------------------------------------------------------------
 template <int COEF, bool PML, bool P2P>
-__global__ __launch_bounds__(FDTD_BLOCK, FDTD_WF_MINBLOCKS) void k_step(const DevParams p, const long long step, const int lag, const unsigned wf_target,
+__global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_MINBLOCKS) void k_step(const DevParams p, const long long step, const int lag, const unsigned wf_target,
                                                                         const unsigned nbp, const FastDiv fd_2m, const int down, const unsigned nmain) {
   extern __shared__ float2 s_lut[];
   __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : FDTD_BLOCK / 2];   // (the probe blocks borrow it for their reduction)
