@@ -808,10 +808,12 @@ static bool wavefront_active(const fdtd_ctx* c) {
   return (size_t)(c->d.nk + 2) * c->plane * 6 * sizeof(float) > ((size_t)FDTD_WF_AUTO_MIB << 20);
 }
 
+static void p2p_prime_if_needed(fdtd_ctx* c);
 static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   HIPCK(c, hipSetDevice(c->d.device));
   hipStream_t s = c->stream;
   for (int n = 0; n < nsteps; ++n) {
+    p2p_prime_if_needed(c);
     if (pe) { c->kev0 = pe->e0[n]; c->kev1 = pe->e1[n]; }
     int r = launch_step_wf(c, c->step, s);
     c->kev0 = c->kev1 = nullptr;
@@ -861,8 +863,16 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
 
 // P2P mailbox transport: the halos travel inside the update kernels, so a step is two launches on ONE stream —
 // no communication stream, no events, no RCCL call; neighbouring ranks couple only through the mailbox flags.
+// p2p transport, before the first timestep: the halo of "step -1" = the INITIAL Ix, Iy of this slab's top plane goes up
+static void p2p_prime_if_needed(fdtd_ctx* c) {
+  if (!c->p.p2p || c->step != 0 || c->p2p_primed) return;
+  hipSetDevice(c->d.device);
+  launch_p2p_prime(c, c->stream);
+  c->p2p_primed = true;
+}
 static int p2p_enqueue_E(fdtd_ctx* c, ProfEvents* pe, int n) {
   HIPCK(c, hipSetDevice(c->d.device));
+  p2p_prime_if_needed(c);
   if (pe) { c->kev0 = pe->e0[n]; c->kev1 = pe->e1[n]; }
   launch_update_E(c, 0, c->d.nk, c->step, true, true, c->stream);
   c->kev0 = c->kev1 = nullptr;
@@ -1246,7 +1256,7 @@ int fdtd_p2p_selftest(fdtd_ctx* c, unsigned token) {
   unsigned res[4] = {0, 0, 0, 0};
   hipError_t e = hipMemcpyAsync(res, d_res, sizeof(res), hipMemcpyDeviceToHost, c->stream);
   // every granule of the neighbours' patterns has been seen in THIS mailbox (or the test has failed): restore the zeros
-  // the first timestep expects (the halo of "step -1" is the zero initial field with tag 0)
+  // (tag 0 = no halo: the first timestep's halo of "step -1" is pushed by k_p2p_prime)
   if (e == hipSuccess) p2p_zero(c, false);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   hipFree(d_res);
@@ -1320,6 +1330,7 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
   const bool multi = n > 1 || (ctxs[0]->d.flags & FDTD_FLAG_LOOPBACK);
   if (ctxs[0]->p.p2p) {   // mailbox transport between contexts of this process: interleave the ranks' launches
     for (int r = 0; r < n; ++r) if (!ctxs[r]->p.p2p || ctxs[r]->any_mur) return fdtd_fail(ctxs[r], FDTD_E_STATE, "fdtd_run_linked: every context must use the p2p transport (no Mur)");
+    for (int r = 0; r < n; ++r) p2p_prime_if_needed(ctxs[r]);   // every rank's initial halo is on its way before any rank's first launch
     const bool wf = wavefront_active(ctxs[0]);
     for (int r = 1; r < n; ++r) if (wavefront_active(ctxs[r]) != wf) return fdtd_fail(ctxs[r], FDTD_E_STATE, "fdtd_run_linked: the contexts disagree on the kernel schedule (set fdtd_desc.flags alike)");
     for (int s = 0; s < nsteps; ++s) {
@@ -1423,6 +1434,7 @@ int fdtd_set_field(fdtd_ctx* c, int kind, int comp, const float* in) {
   HIPCK(c, hipSetDevice(c->d.device));
   HIPCK(c, hipStreamSynchronize(c->stream));
   c->mur_pre_step = -1;   // a Mur pre pass computed on the old voltages is void
+  c->p2p_primed = false;  // ... and so is an initial halo pushed from the old fields
   float* dst = kind == FDTD_KIND_V ? c->p.V[comp] : c->p.I[comp];
   HIPCK(c, hipMemcpy2D(dst, (size_t)c->P * 4, in, (size_t)c->d.nx * 4, (size_t)c->d.nx * 4, (size_t)c->d.nk * c->d.ny,
                        hipMemcpyHostToDevice));

@@ -124,6 +124,7 @@ struct fdtd_ctx {
   bool mbox_fine = false;                          // fine-grained (system-coherent) device memory
   void* peer_lo = nullptr; void* peer_hi = nullptr; // neighbours' mailboxes (IPC mappings or in-process pointers)
   bool peer_lo_ipc = false, peer_hi_ipc = false;
+  bool p2p_primed = false;       // the initial top-plane Ix, Iy have been pushed to the upper rank (k_p2p_prime)
   // one launch per timestep (wavefront schedule, k_step)
   int wf_mode = -1;              // -1 auto (grids beyond the Infinity Cache), 0 off, 1 on; $FDTD_WAVEFRONT
   int wf_lag = 0;                // planes the E sweep runs ahead (0: auto); $FDTD_WF_LAG
@@ -197,6 +198,7 @@ void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool p
 // one launch = E and H half-step of all planes (single slab, no Mur, fusable sources); probes are sampled by launch_probes
 int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s);
 int wf_lag_for(const fdtd_ctx* c);
+void launch_p2p_prime(fdtd_ctx* c, hipStream_t s);   // p2p transport, before step 0: initial Ix, Iy of the top plane -> upper rank's mailbox
 void launch_probes(fdtd_ctx* c, long long step, hipStream_t s);   // V- and I-probes of `step` in one launch (stand-alone form)
 int build_mur_table(fdtd_ctx* c);   // after fdtd_set_mur: face table -> device
 void launch_mur(fdtd_ctx* c, int mode, hipStream_t s);

@@ -67,7 +67,8 @@ __device__ __forceinline__ void decode_block_fd(const FastDiv& fd_ps, const Fast
   strip = (int)s; kk = (int)k; pb = (int)(rem - k * fd_nbs.d);
 }
 // ---- P2P mailbox protocol -------------------------------------------------------------------------------------------
-// A halo value travels as an 8-byte GRANULE {value, tag}: tag = number of the timestep whose half-step produced it (+1), in
+// A halo value travels as an 8-byte GRANULE {value, tag}: tag = number of the timestep whose half-step produced it (+1 for E, +2 for
+// H: the H halo of step s is what the E sweep of step s+1 expects under tag s+2; 0 is never a valid tag), in
 // the same naturally aligned 8 bytes as the value, so whoever sees the tag sees the value.  No flag, no arrival counter, no
 // wait for store acknowledgements on the producer; ONE round trip on the consumer (it loads the granules together with its
 // field loads and looks at the tags; only a late neighbour makes it load again).  The earlier protocol — payload stores,

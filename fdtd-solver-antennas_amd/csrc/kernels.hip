@@ -144,9 +144,9 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
   }
   if (PML && FDTD_PSI_STAGE)   // psi of the x / z layers: LDS-DMA right behind the field loads (kernel_common.hpp)
     psi_stage_issue(p, p.psiE, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
-  if (dep_in) {   // H halo of step-1 (tag = step: the zero initial field for step 0); slot of the parity of the step that produced it
+  if (dep_in) {   // H halo of step-1 (tag = step + 1; for step 0 the neighbour's INITIAL top plane, pushed by k_p2p_prime); slot of the parity of the step that produced it
     const float* mb = p.mb_in_H + (size_t)((step + 1) & 1) * 2 * mb_slot_words(p);
-    mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step, ix_km, iy_km, p.p2p_err, p.p2p_limit);
+    mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u, ix_km, iy_km, p.p2p_err, p.p2p_limit);
   }
 
   // component x: d1 along y (of Iz), d2 along z (of Iy); y: d1 along z (Ix), d2 along x (Iz);
@@ -421,8 +421,8 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
   else { sto4s(p.nt, p.I[0], uo, ix); sto4s(p.nt, p.I[1], uo, iy); sto4s(p.nt, p.I[2], uo, iz); }
   if (P2P && k == p.nk - 1 && p.mb_out_H != nullptr) {   // push the new Ix, Iy of the top plane into the upper rank's mailbox
     float* mb = p.mb_out_H + (size_t)(step & 1) * 2 * mb_slot_words(p);
-    mb_push(mb, (unsigned)(j * p.P + i0), (unsigned)step + 1u, ix);
-    mb_push(mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u, iy);
+    mb_push(mb, (unsigned)(j * p.P + i0), (unsigned)step + 2u, ix);
+    mb_push(mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 2u, iy);
   }
   }   // valid
   if (pub) wf_publish(p, p.wf_flagsH, k, strip, pb, wf_target);
@@ -552,6 +552,19 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_post(const DevParams p, const in
     __syncthreads();  // single block: sources land before the probes read
   }
   probe_block(p, kind, step, red);
+}
+
+// Before the first timestep of a decomposed run: the E sweep of step 0 reads, as its k-1 neighbours of plane 0, the INITIAL
+// Ix, Iy of the lower rank's top plane.  Every rank pushes them up (tag 1, the slot of "step -1"), so seeded initial fields
+// decompose like zero ones; a zero tag is never valid, i.e. an untouched mailbox can never be mistaken for a halo.
+__global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_prime(const DevParams p) {
+  const unsigned t = blockIdx.x * FDTD_BLOCK + threadIdx.x;
+  if (t >= (unsigned)p.plane / 4u || !p.mb_out_H) return;
+  const unsigned o = 4u * t;
+  const size_t top = (size_t)(p.nk - 1) * p.plane + o;
+  float* mb = p.mb_out_H + (size_t)1 * 2 * mb_slot_words(p);
+  mb_push(mb, o, 1u, ld4(p.I[0] + top));
+  mb_push(mb + mb_slot_words(p), o, 1u, ld4(p.I[1] + top));
 }
 
 // V- and I-probes of one step in one launch, one block per probe (wavefront schedule: both fields are final when the step's
@@ -867,6 +880,10 @@ int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s) {
     else launch_step2<2, false>(c, step, lag, s);
   }
   return FDTD_OK;
+}
+
+void launch_p2p_prime(fdtd_ctx* c, hipStream_t s) {
+  hipLaunchKernelGGL(k_p2p_prime, dim3((unsigned)((c->plane / 4 + FDTD_BLOCK - 1) / FDTD_BLOCK)), dim3(FDTD_BLOCK), 0, s, c->p);
 }
 
 void launch_probes(fdtd_ctx* c, long long step, hipStream_t s) {
