@@ -848,6 +848,11 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_p2p_attach (mailbox transport), fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
   if (wavefront_active(c)) return step_loop_wf(c, nsteps, pe);
   const bool fused = sources_fusable(c);
+  if (multi && c->step == 0 && !c->p2p_primed) {   // the H halo of "step -1": the initial fields (runs from non-zero fields decompose too)
+    int r = exchange(c, FDTD_HALO_H_UP);
+    if (r) return r;
+    c->p2p_primed = true;
+  }
   for (int n = 0; n < nsteps; ++n) {
     int r = phase_E(c, multi, fused, pe, n);
     if (r) return r;
@@ -1360,6 +1365,14 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
     }
     return FDTD_OK;
   }
+  if (multi)   // the H halo of "step -1": the initial fields
+    for (int r = 0; r < n; ++r) {
+      fdtd_ctx* c = ctxs[r];
+      if (c->step != 0 || c->p2p_primed) continue;
+      int rc = exchange(c, FDTD_HALO_H_UP);
+      if (rc) return rc;
+      c->haloH_issued = true; c->p2p_primed = true;
+    }
   for (int s = 0; s < nsteps; ++s) {
     int rc;
     for (int r = 0; r < n; ++r) if ((rc = phase_E(ctxs[r], multi, sources_fusable(ctxs[r]), nullptr, 0))) return rc;

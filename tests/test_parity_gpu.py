@@ -173,10 +173,18 @@ def test_linked_slabs_overlapped_schedule(hip_lib, world, overlap):
     capi = pkg("_capi")
     s1 = patch_sim(56, 52, 34, nr_ts=260)
     e1 = s1.build(hip_lib)
-    e1.run(260)
     sims = [patch_sim(56, 52, 34, nr_ts=260) for _ in range(world)]
     flag = capi.FLAG_OVERLAP_ON if overlap == "split" else capi.FLAG_OVERLAP_OFF
     engs = [s.build(hip_lib, rank=r, world=world, flags=flag) for r, s in enumerate(sims)]
+    if world != 3:      # random INITIAL fields (zero ones for world 3): the first exchange happens before the first half-step
+        rng = np.random.default_rng(6)
+        for kind in (0, 1):
+            for comp in range(3):
+                g = (1e-3 * rng.standard_normal(e1.local_shape)).astype(np.float32)
+                e1.set_field(kind, comp, g)
+                for e in engs:
+                    e.set_field(kind, comp, np.ascontiguousarray(g[e.k0:e.k0 + e.nk]))
+    e1.run(260)
     for n in (1, 100, 159):
         capi.run_linked(engs, n)
     f1, f2 = e1.fields(), np.concatenate([e.fields() for e in engs], axis=2)
@@ -351,6 +359,7 @@ def test_rccl_self_loopback_transport(hip_lib, oracle_lib, overlap):
     outs = [er.fields()]
     for lib in (hip_lib, oracle_lib):
         _, e = slab(lib, 0)
+        e.halo_put(capi.HALO_H_UP, e.halo_get(capi.HALO_H_UP))     # the halo of "step -1": the (seeded) initial fields
         for _ in range(n):
             e.half_step(capi.PHASE_E)
             e.halo_put(capi.HALO_E_DOWN, e.halo_get(capi.HALO_E_DOWN))
