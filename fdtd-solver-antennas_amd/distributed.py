@@ -144,6 +144,8 @@ class SlabComm:
         self.ms_exchange += (time.perf_counter() - t0) * 1e3
 
     def run_steps(self, eng, nsteps: int):
+        if nsteps > 0 and int(eng.step) == 0:      # the H halo of "step -1": the initial fields (non-zero initial fields decompose too)
+            self.exchange(eng, _capi.HALO_H_UP)
         for _ in range(nsteps):
             eng.half_step(_capi.PHASE_E)
             self.exchange(eng, _capi.HALO_E_DOWN)
