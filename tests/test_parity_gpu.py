@@ -739,7 +739,7 @@ def test_wavefront_schedule_refuses_what_it_cannot_do(hip_lib):
 
 
 @pytest.mark.parametrize("shape,tys", [((37, 300, 10), 0), ((37, 300, 10), 4), ((64, 60, 36), 40), ((53, 47, 31), 5),
-                                       ((1028, 9, 9), 0), ((260, 18, 40), 7)])
+                                       ((1028, 9, 9), 0), ((260, 18, 40), 7), ((16, 9, 12), 0), ((24, 12, 9), 4)])
 def test_wavefront_schedule_odd_tilings_equal_two_launches(hip_lib, shape, tys, monkeypatch):
     """The flag sets of the one-launch schedule under unusual tilings — 25 rows per block, one-row strips' worth of blocks,
     strips of 4 / 5 / 7 / 40 rows ($FDTD_TYS), a short last strip, rows longer than a block, more blocks per plane group than
