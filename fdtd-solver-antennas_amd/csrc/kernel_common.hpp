@@ -80,11 +80,6 @@ __device__ __forceinline__ void decode_block_fd(const FastDiv& fd_ps, const Fast
 // one reads it).  Slots alternate with the parity of the step, so a value is overwritten two steps later — by then the
 // writer has consumed the reader's own halo of the step in between, which the reader produced after reading this one.
 typedef float v4f_sys __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld4_sys(const float* q) {
-  v4f_sys r;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(q) : "memory");   // early clobber: the destination never shares registers with the address
-  return make_float4(r.x, r.y, r.z, r.w);
-}
 // The s_nop is part of the instruction's contract here: a vector-memory store of more than 64 bits reads its data
 // registers AFTER issue, and a VALU write to them in the next wait states corrupts what the later lanes store (hipcc pads
 // its own stores; it cannot see into an asm statement).  Found by the data-path self-test of the mailbox transport.
