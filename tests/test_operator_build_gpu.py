@@ -70,3 +70,40 @@ def test_fields_same_on_device_and_host_set_up(hip_lib, oracle_lib, use_classes)
     if use_classes:          # a voxelised patch scene has a handful of classes: one byte per CELL on the device
         assert eh.operator_form()[0] == "classes-packed" and eh_host.operator_form()[0] == "classes-packed"
         assert eh.operator_form()[1] == eh_host.operator_form()[1] == eo.operator_form()[1]
+
+
+@pytest.mark.parametrize("schedule", ["two_launches", "one_launch"])
+def test_stepping_in_every_operator_form_equals_the_oracle(hip_lib, oracle_lib, schedule):
+    """The update kernels with ONE CLASS BYTE PER EDGE (scenes with more than 256 distinct class triples: random PEC edges,
+    uncorrelated single-cell materials) and with raw coefficient arrays, stepped 60 timesteps from random fields under both
+    kernel schedules: fields identical to the oracle's (which steps the expanded coefficients).  The packed one-byte-per-cell
+    form is what every patch scene of the suite runs in."""
+    capi, eco, simm, const = pkg("_capi"), pkg("ecoperator"), pkg("simulation"), pkg("constants")
+    flags = capi.FLAG_KERNEL_DIRECT if schedule == "two_launches" else capi.FLAG_KERNEL_WAVEFRONT
+    grid, eps, kap, pec, lumped = random_scene(1, (30, 26, 18), False, 3)
+    dt = grid.courant_dt()
+    nx, ny, nz = grid.shape
+    rng = np.random.default_rng(0)
+    pal_e, pal_k = np.array([1.0, 2.2, 4.3, 9.8, 6.15, 3.38]), np.array([0.0, 1e-3, 2e-3, 0.0, 5e-3, 0.1])
+    mat = rng.integers(0, 6, size=(nz - 1, ny - 1, nx - 1))
+    mat[:, :, : (nx - 1) // 2] = 0
+    cases = {"per-edge, random PEC": (eps, kap, True), "per-edge, six materials": (pal_e[mat], pal_k[mat], True), "raw": (eps, kap, False)}
+    seen = set()
+    for name, (e_r, k_r, prefer) in cases.items():
+        engs = []
+        for lib, fl in ((hip_lib, flags), (oracle_lib, 0)):
+            e = capi.Engine(lib, nx, ny, nz, dt, max_steps=8, flags=fl)
+            emet, hmet = eco.pack_metric_tables(*eco.metric_lists(grid, dt), grid, 0, nz)
+            e.build_operator(grid.d, e_r, k_r, pec, const.EPS0, eco.lumped_overrides(grid, e_r, k_r, pec, dt, lumped), emet, hmet,
+                             prefer_classes=prefer)
+            frng = np.random.default_rng(3)
+            for kind in (0, 1):
+                for c in range(3):
+                    e.set_field(kind, c, (1e-3 * frng.standard_normal(e.local_shape)).astype(np.float32))
+            e.run(60)
+            engs.append(e)
+        seen.add(engs[0].operator_form()[0])
+        fh, fo = engs[0].fields(), engs[1].fields()
+        assert np.isfinite(fo).all() and np.abs(fo).max() > 0
+        assert np.array_equal(fh, fo), f"{name} ({engs[0].operator_form()}): {np.abs(fh - fo).max():.3e}"
+    assert seen == {"classes", "raw"}, seen
