@@ -63,8 +63,11 @@ def test_fields_bitexact_cpml_thick_x_layers(hip_lib, oracle_lib):
     assert np.abs(fo).max() > 0 and same_values(fh, fo), f"rel L2 {rel_l2(fh, fo):.3e}"
 
 
-def test_fields_bitexact_mur(hip_lib, oracle_lib):
-    (sh, eh), (so, eo) = _run_both(lambda: patch_sim(48, 44, 30, boundary="MUR", nr_ts=400), hip_lib, oracle_lib, 400, seed=2)
+@pytest.mark.parametrize("use_classes,shape", [(True, (48, 44, 30)), (False, (48, 44, 30)), (True, (53, 47, 31))])
+def test_fields_bitexact_mur(hip_lib, oracle_lib, use_classes, shape):
+    """First-order Mur on all six faces (the post pass rides in update_E, the pre pass in update_H): class and raw operator,
+    nx a multiple of 4 and not."""
+    (sh, eh), (so, eo) = _run_both(lambda: patch_sim(*shape, boundary="MUR", nr_ts=400, use_classes=use_classes), hip_lib, oracle_lib, 400, seed=2)
     fh, fo = eh.fields(), eo.fields()
     assert same_values(fh, fo), f"rel L2 {rel_l2(fh, fo):.3e}"
     nz = fo != 0
