@@ -228,7 +228,8 @@ def roofline_block(workload, eng, prof, world, host_transport, ms_timestep):
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
            "traffic_source": source, "kernel": dom, "ms_update_E": round(ms_e, 5), "ms_update_H": round(ms_h, 5),
            "algorithmic_bytes_per_launch": algo_bytes,
-           "schedule": "one launch per timestep (k_step: E sweep a few planes ahead of the H sweep)" if one_launch else "two launches per timestep",
+           "schedule": ("one launch per timestep (k_step: all E blocks, then all H blocks; beyond the Infinity Cache the H sweep a few planes behind the E sweep)"
+                        if one_launch else "two launches per timestep"),
            "kernel_timing": "dispatch begin/end timestamps (start/stop events on every main launch), nothing subtracted",
            "ms_per_timestep_profiled": round(ms_ts, 5),
            # the 256 MiB Infinity Cache holds the whole working set of the smaller grids: their 'HBM' rate is a cache rate

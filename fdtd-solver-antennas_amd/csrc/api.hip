@@ -802,10 +802,15 @@ static bool wavefront_active(const fdtd_ctx* c) {
   if (!wavefront_possible(c) || sel == FDTD_FLAG_KERNEL_DIRECT) return false;
   if (sel == FDTD_FLAG_KERNEL_WAVEFRONT) return true;
   if (c->wf_mode >= 0) return c->wf_mode != 0;
-  // (thin slabs of a decomposed grid, where every block of a timestep is resident at once, were the other candidate: measured
-  // on an 8-plane north-star slab whose halos go to itself, one launch takes 30-37 us per step against 28 us for two — the
-  // chain E block -> flag -> poll -> sc1 loads -> H block is longer than a kernel boundary.  Not chosen.)
-  return (size_t)(c->d.nk + 2) * c->plane * 6 * sizeof(float) > ((size_t)FDTD_WF_AUTO_MIB << 20);
+  // single slab: always (beyond the Infinity Cache with H a few planes behind E, below it with all E blocks first: wf_lag_for).
+  // Slabs of a decomposed grid on the mailbox transport: only beyond the Infinity Cache (a thin slab whose halos go to itself
+  // steps in 20-21 us with one launch against 17.6 us with two: the hand-off behind flags plus the halo granules make a
+  // longer chain than a kernel boundary).
+  const bool big = (size_t)(c->d.nk + 2) * c->plane * 6 * sizeof(float) > ((size_t)FDTD_WF_AUTO_MIB << 20);
+  // (small grids WITHOUT CPML are the exception: their half-step kernels are so short that the flags cost more than the kernel
+  // boundary saves — 200x200x40 without CPML: 83.5 Gcells/s with two launches, 76.5 with one; with CPML 55.6 -> 57.1)
+  if (c->d.world == 1) return big || c->have_cpml || (size_t)c->d.nk * c->p.nstrips * c->p.nbs >= 3000;
+  return big;
 }
 
 static void p2p_prime_if_needed(fdtd_ctx* c);

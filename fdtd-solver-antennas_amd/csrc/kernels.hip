@@ -26,6 +26,7 @@
 // identical to oracle/fdtd_oracle.c, so results are compared bit for bit.
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "kernel_common.hpp"
@@ -479,21 +480,41 @@ __global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_M
     wf_probe_tail(p, (int)(b - nmain), step, wf_target, reinterpret_cast<double*>(s_psi));
     return;
   }
-  const unsigned m = fd_2m.d >> 1;                    // positions per role in a plane group (the largest XCD share of a plane)
-  const unsigned grp = fd_div(pos, fd_2m), w = pos - grp * fd_2m.d;
-  const bool is_h = w >= m;
-  const unsigned r = is_h ? w - m : w;
-  int k = is_h ? (int)grp - lag : (int)grp;
-  // this XCD group's contiguous share of the plane's nbp = nstrips * nbs blocks
-  const unsigned q = nbp >> 3, rem = nbp & 7u;
-  const unsigned cnt = q + (x < rem ? 1u : 0u), first = x * q + (x < rem ? x : rem);
-  if (k < 0 || k >= p.nk || r >= cnt) return;
-  // odd steps walk the planes downwards: a step starts on the planes the previous one touched last (still in the Infinity
-  // Cache).  The flags an H block waits for — planes k and k + 1 — are earlier in dispatch order in either direction.
-  if (down) k = p.nk - 1 - k;
-  const unsigned v = first + r;
-  const unsigned strip = fd_div(v, p.fd_nbs);
-  const int pb = (int)(v - strip * p.fd_nbs.d);
+  bool is_h;
+  int k, pb;
+  unsigned strip;
+  if (lag < 0) {
+    // Cache-resident slab: ALL E blocks, then ALL H blocks, each half in the two-launch kernels' own order (XCD-contiguous,
+    // strip-major; fd_2m is the divider nk * nbs here; odd steps walk every XCD's range backwards).  No empty positions: on
+    // planes of a few dozen blocks the plane-group order below dispatches more empty blocks than real ones.
+    const unsigned nE = nmain >> 1;
+    is_h = b >= nE;
+    const unsigned bb = is_h ? b - nE : b;
+    const unsigned q = nE >> 3, r = nE & 7u, xcd = bb & 7u;
+    unsigned ps = bb >> 3;
+    if (down) ps = (xcd < r ? q : q - 1u) - ps;
+    const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ps;
+    strip = fd_div(v, fd_2m);
+    const unsigned rem = v - strip * fd_2m.d;
+    const unsigned kk = fd_div(rem, p.fd_nbs);
+    k = (int)kk; pb = (int)(rem - kk * p.fd_nbs.d);
+  } else {
+    const unsigned m = fd_2m.d >> 1;                    // positions per role in a plane group (the largest XCD share of a plane)
+    const unsigned grp = fd_div(pos, fd_2m), w = pos - grp * fd_2m.d;
+    is_h = w >= m;
+    const unsigned r = is_h ? w - m : w;
+    k = is_h ? (int)grp - lag : (int)grp;
+    // this XCD group's contiguous share of the plane's nbp = nstrips * nbs blocks
+    const unsigned q = nbp >> 3, rem = nbp & 7u;
+    const unsigned cnt = q + (x < rem ? 1u : 0u), first = x * q + (x < rem ? x : rem);
+    if (k < 0 || k >= p.nk || r >= cnt) return;
+    // odd steps walk the planes downwards: a step starts on the planes the previous one touched last (still in the Infinity
+    // Cache).  The flags an H block waits for — planes k and k + 1 — are earlier in dispatch order in either direction.
+    if (down) k = p.nk - 1 - k;
+    const unsigned v = first + r;
+    strip = fd_div(v, p.fd_nbs);
+    pb = (int)(v - strip * p.fd_nbs.d);
+  }
   // P2P (mailbox halo transport, upwards only): E of plane 0 — the first blocks of the launch — takes its k-1 neighbours from
   // the lower rank's mailbox and pushes its result down; H of the top plane — the last H blocks — takes k+1 from the upper
   // rank's mailbox (that rank's E blocks of plane 0 are the first of ITS launch) and pushes its result up.
@@ -687,14 +708,36 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_energy(const DevParams p, double
 void choose_tiling(fdtd_ctx* c) {
   // rows per strip: minimise idle lanes in the last block of a strip-plane, prefer ~16 rows
   const int P4 = c->p.P4, ny = c->p.ny;
+  // One launch per timestep (k_step): every XCD group takes an equal share of each plane's blocks and the groups advance in
+  // step (flags), so what counts there is the plane as a whole — blocks wasted on a short last strip and shares that differ
+  // by a block stall everybody (400x400x80: 23-row strips = 18 strips, the last of 9 rows, 162 blocks = shares of 20 and 21:
+  // 66 Gcells/s; 40-row strips = 160 blocks = 8 x 20: 70).
+  const unsigned sel = c->d.flags & FDTD_FLAG_KERNEL_MASK;
+  const bool wf_big = (size_t)(c->d.nk + 2) * c->plane * 6 * sizeof(float) > ((size_t)FDTD_WF_AUTO_MIB << 20);
+  // (cache-resident slabs run all E blocks, then all H blocks, each half in the two-launch order: the two-launch rule fits them —
+  // 300x300x60 in one launch: 75.7 Gcells/s with its 17-row strips, 72-74 with 10, 15, 20, 25, 30 or 40 rows)
+  const bool wf_like = wf_big && sel != FDTD_FLAG_KERNEL_DIRECT;
   int best = 1; double best_cost = 1e30;
   for (int tys = 4; tys <= 40; ++tys) {
-    const int t = (tys < ny ? tys : ny) * P4;
+    const int rows = tys < ny ? tys : ny;
+    const int t = rows * P4;
     const int nbs = (t + FDTD_BLOCK - 1) / FDTD_BLOCK;
-    const double idle = (double)(nbs * FDTD_BLOCK - t) / (nbs * FDTD_BLOCK);
     const double halo = 1.0 / tys * 0.15;   // j-neighbour rows re-read at strip seams (L2-served)
-    const double cost = idle + halo;
-    if (cost < best_cost - 1e-12) { best_cost = cost; best = tys < ny ? tys : ny; }
+    double cost;
+    if (wf_like) {
+      // the plane as a whole: lanes wasted in every strip's last block AND on a short last strip (whose trailing blocks are
+      // dispatched empty), a short last strip as such (measured: 300 rows in strips of 17 / 20 rows = the same 90 blocks per
+      // plane, 73.5 / 74.8 Gcells/s), and — beyond the Infinity Cache, where the XCD groups advance in step — uneven shares
+      const int nstrips = (ny + rows - 1) / rows;
+      const double nbp = (double)nstrips * nbs;
+      const double waste = 1.0 - (double)ny * P4 / (nbp * FDTD_BLOCK);
+      const double ragged = (ny % rows) ? 0.02 : 0.0;
+      const double uneven = wf_big ? (8.0 * std::ceil(nbp / 8.0) - nbp) / nbp : 0.0;
+      cost = waste + ragged + uneven + halo;
+    } else {
+      cost = (double)(nbs * FDTD_BLOCK - t) / (nbs * FDTD_BLOCK) + halo;
+    }
+    if (cost < best_cost - 1e-12) { best_cost = cost; best = rows; }
   }
   if (const char* e = getenv("FDTD_TYS")) { const int v = atoi(e); if (v >= 1 && v <= 65536) best = v < ny ? v : ny; }   // experiments
   c->p.tys = best;
@@ -793,6 +836,11 @@ void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool p
 // (measured with the streaming stand-in: smaller stalls the H blocks, larger gives the Infinity Cache away).
 int wf_lag_for(const fdtd_ctx* c) {
   if (c->wf_lag > 0) return c->wf_lag;
+  // cache-resident slab: nothing to gain from H following E closely (the L2s are far too small for the resident-block window),
+  // something to lose (write-through V leaves L2; waiting H blocks occupy the chip): all E blocks first, then all H blocks —
+  // what is left is one launch instead of two: no kernel boundary, H blocks start while the last E blocks drain
+  // (300x300x60: 72.5 -> 74.8 Gcells/s, 200x200x40: 56.5 -> 60.3)
+  if ((size_t)(c->d.nk + 2) * c->plane * 6 * sizeof(float) <= ((size_t)FDTD_WF_AUTO_MIB << 20)) return c->d.nk;
   const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs, m = (nbp + 7u) / 8u;
   const unsigned resident = 256u * (unsigned)(c->occ_wf > 0 && c->occ_wf < FDTD_WF_MINBLOCKS ? c->occ_wf : FDTD_WF_MINBLOCKS);
   return (int)((resident + 16u * m - 1u) / (16u * m)) + 2;
@@ -802,11 +850,17 @@ template <int COEF, bool PML, bool P2P>
 static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s) {
   const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs, m = (nbp + 7u) / 8u;
   const unsigned lut_bytes = (unsigned)(c->raw_op ? 0 : (c->p.lut_n + 1) / 2) * 16u;
+  const unsigned pad = lut_bytes + lds_pad(c->occ_wf, (PML && FDTD_PSI_STAGE ? 20480u : 2560u) + lut_bytes);
+  const int down = (!P2P && c->p.sweep_rev && (step & 1)) ? 1 : 0;
+  if (lag >= c->p.nk) {   // all E blocks, then all H blocks (cache-resident slabs: wf_lag_for)
+    const unsigned nE = nbp * (unsigned)c->p.nk;
+    launch_main(c, k_step<COEF, PML, P2P>, dim3(2u * nE + (unsigned)c->nprobe), pad, s, c->p, step, -1, c->wf_epoch, nbp,
+                make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), down, 2u * nE);
+    return;
+  }
   const unsigned nmain = 8u * 2u * m * (unsigned)(c->p.nk + lag);
   const dim3 grid(nmain + (unsigned)c->nprobe);
-  const unsigned pad = lut_bytes + lds_pad(c->occ_wf, (PML && FDTD_PSI_STAGE ? 20480u : 2560u) + lut_bytes);
-  launch_main(c, k_step<COEF, PML, P2P>, grid, pad, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m),
-              (!P2P && c->p.sweep_rev && (step & 1)) ? 1 : 0, nmain);
+  launch_main(c, k_step<COEF, PML, P2P>, grid, pad, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m), down, nmain);
 }
 template <int COEF, bool PML>
 static void launch_step2(fdtd_ctx* c, long long step, int lag, hipStream_t s) {
