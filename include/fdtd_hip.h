@@ -68,15 +68,15 @@ enum { FDTD_HALO_H_UP = 0, FDTD_HALO_E_DOWN = 1 };   /* Ix,Iy top plane -> rank+
 
 /* Kernel selection (fdtd_desc.flags). */
 enum {
-  FDTD_FLAG_KERNEL_AUTO   = 0,   /* the two-pass kernels (one E launch + one H launch per step); the wavefront schedule below on large single slabs */
+  FDTD_FLAG_KERNEL_AUTO   = 0,   /* the schedule measured faster: one launch per step (below) on single slabs without Mur faces, else two */
   FDTD_FLAG_KERNEL_DIRECT = 1,   /* the same, named explicitly */
   /* 2..4 were one-pass (fused E+H) variants — per-thread recompute, overlapped LDS tiles, z-marching tiles (round 1), and a
      z-marching kernel on an LDS-DMA ring (round 2, git history).  All were bit-exact and all measured slower than the two
      passes (profiles/r01, profiles/r02/one_pass_*); none ships: selecting them is FDTD_E_UNSUPPORTED. */
   FDTD_FLAG_KERNEL_WAVEFRONT = 5, /* ONE launch per timestep: the E sweep runs a few planes ahead of the H sweep, coupled by per-block
                                     flags, so that H reads what E just touched from the Infinity Cache instead of HBM.  Single slab, or
-                                    slabs on the p2p mailbox transport; no Mur faces (else FDTD_E_UNSUPPORTED).  AUTO picks it for
-                                    slabs whose fields exceed the Infinity Cache; DIRECT never does.  Results are identical to the
+                                    slabs on the p2p mailbox transport; no Mur faces (else FDTD_E_UNSUPPORTED).  Below 256 MiB of fields all E blocks
+                                    run first, then all H blocks.  DIRECT never takes it.  Results are identical to the
                                     two-pass kernels bit for bit.  fdtd_profile.fused = 1: ms_update_e is the whole timestep's launch. */
   FDTD_FLAG_KERNEL_MASK   = 0xF,
   FDTD_FLAG_NO_GRAPH      = 0x10, /* reserved */
