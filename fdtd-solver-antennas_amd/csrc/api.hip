@@ -809,8 +809,11 @@ static bool wavefront_active(const fdtd_ctx* c) {
   const bool big = (size_t)(c->d.nk + 2) * c->plane * 6 * sizeof(float) > ((size_t)FDTD_WF_AUTO_MIB << 20);
   // (small grids WITHOUT CPML are the exception: their half-step kernels are so short that the flags cost more than the kernel
   // boundary saves — 200x200x40 without CPML: 83.5 Gcells/s with two launches, 76.5 with one; with CPML 55.6 -> 57.1)
-  if (c->d.world == 1) return big || c->have_cpml || (size_t)c->d.nk * c->p.nstrips * c->p.nbs >= 3000;
-  return big;
+  const size_t blocks = (size_t)c->d.nk * c->p.nstrips * c->p.nbs;   // per sweep
+  if (c->d.world == 1) return big || c->have_cpml || blocks >= 3000;
+  // slabs on the mailbox transport: when a sweep is more than one round of resident blocks (an interior north-star slab whose
+  // halos go to itself: 20 planes 29.5 -> 25.3 us per step with one launch; 15 planes 23.3 -> 25.4, 8 planes 17.8 -> 19.8)
+  return big || blocks >= 1800;
 }
 
 static void p2p_prime_if_needed(fdtd_ctx* c);

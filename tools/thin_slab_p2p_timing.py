@@ -7,7 +7,7 @@ capi = importlib.import_module(PKG + "._capi"); wl = importlib.import_module(PKG
 sc = importlib.import_module(PKG + ".scene"); simm = importlib.import_module(PKG + ".simulation")
 hip = capi.load_hip_library()
 w = wl.baseline_workload("NS"); vox = sc.voxelize(w.scene, w.grid)
-for world in (4, 8):
+for world in tuple(int(x) for x in os.environ.get("WORLDS", "4,8").split(",")):
     sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=10, nr_ts=9000, nf2ff_freqs=[w.f0])
     e = sim.build(hip, rank=1, world=world)
     blob = e.p2p_export(); e.p2p_attach(blob, blob)
