@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "fdtd_operator_form", "fdtd_get_operator", "fdtd_set_cpml",
     "fdtd_set_mur", "fdtd_set_signal", "fdtd_add_source", "fdtd_add_probe", "fdtd_get_probe",
     "fdtd_set_dft", "fdtd_add_dft_box", "fdtd_get_dft_box", "fdtd_set_recorder", "fdtd_rec_transform", "fdtd_run", "fdtd_run_profiled",
-    "fdtd_get_step", "fdtd_energy", "fdtd_p2p_export", "fdtd_p2p_attach", "fdtd_p2p_selftest", "fdtd_p2p_detach", "fdtd_comm_unique_id", "fdtd_comm_init", "fdtd_comm_nranks", "fdtd_link", "fdtd_run_linked", "fdtd_half_step",
+    "fdtd_get_step", "fdtd_energy", "fdtd_p2p_export", "fdtd_p2p_attach", "fdtd_p2p_selftest", "fdtd_p2p_detach", "fdtd_p2p_link_info", "fdtd_schedule_info", "fdtd_comm_unique_id", "fdtd_comm_init", "fdtd_comm_nranks", "fdtd_link", "fdtd_run_linked", "fdtd_half_step",
     "fdtd_halo_get", "fdtd_halo_put", "fdtd_get_field", "fdtd_set_field", "fdtd_farfield",
 ]
 
@@ -40,7 +40,7 @@ class FdtdProfile(C.Structure):
                 ("steps", C.c_int32), ("fused", C.c_int32), ("ms_event_overhead", C.c_double)]
 
 
-FLAG_KERNEL_AUTO, FLAG_KERNEL_DIRECT, FLAG_KERNEL_WAVEFRONT, FLAG_NO_GRAPH = 0, 1, 5, 0x10
+FLAG_KERNEL_AUTO, FLAG_KERNEL_DIRECT, FLAG_KERNEL_WAVEFRONT, FLAG_KERNEL_MASK = 0, 1, 5, 0xF
 FLAG_OVERLAP_ON, FLAG_OVERLAP_OFF, FLAG_LOOPBACK = 0x20, 0x40, 0x80
 KIND_V, KIND_I = 0, 1
 PHASE_E, PHASE_H = 0, 1
@@ -83,6 +83,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
         "fdtd_p2p_attach": (C.c_int, [p, p, p]),
         "fdtd_p2p_selftest": (C.c_int, [p, C.c_uint]),
         "fdtd_p2p_detach": (C.c_int, [p]),
+        "fdtd_p2p_link_info": (C.c_int, [p, C.c_int, p]),
+        "fdtd_schedule_info": (C.c_int, [p, p]),
         "fdtd_comm_unique_id": (C.c_int, [p]),
         "fdtd_comm_init": (C.c_int, [p, p]),
         "fdtd_comm_nranks": (C.c_int, [p, C.POINTER(C.c_int)]),
@@ -393,6 +395,25 @@ class Engine:
 
     def p2p_detach(self):
         self._ck(self.lib.fdtd_p2p_detach(self._ctx), "p2p_detach")
+
+    LINK_TYPES = {0: "hypertransport", 1: "qpi", 2: "pcie", 3: "infiniband", 4: "xgmi"}
+
+    def p2p_link_info(self, which: int) -> dict:
+        """The link to the attached lower (which=0) / upper (1) neighbour's GPU (fdtd_p2p_link_info)."""
+        a = np.full(8, -1, np.int32)
+        self._ck(self.lib.fdtd_p2p_link_info(self._ctx, int(which), _ptr(a)), "p2p_link_info")
+        return {"device": int(a[0]), "mapping": {1: "same-process", 2: "ipc"}.get(int(a[1]), None),
+                "link": self.LINK_TYPES.get(int(a[2]), None if a[2] < 0 else f"type{int(a[2])}"), "hops": int(a[3]),
+                "perf_rank": int(a[4]), "access": int(a[5]), "native_atomics": int(a[6]), "same_device": bool(a[7] == 1)}
+
+    def schedule_info(self) -> dict:
+        """Launches per timestep, lag, tiling and halo transport of this context (fdtd_schedule_info)."""
+        a = np.zeros(8, np.int32)
+        self._ck(self.lib.fdtd_schedule_info(self._ctx, _ptr(a)), "schedule_info")
+        return {"launches_per_timestep": int(a[0]), "lag_planes": int(a[1]), "rows_per_strip": int(a[2]),
+                "blocks_per_sweep": int(a[3]),
+                "transport": ("none", "p2p", "rccl", "linked", "external")[int(a[4])] if 0 <= a[4] <= 4 else None,
+                "xcd_shares_weighted": bool(a[5])}
 
     def comm_nranks(self) -> int:
         """Ranks of the RCCL communicator attached to this context (0: none)."""

@@ -156,7 +156,8 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
     CK(hipMalloc(&c->fieldbase[n], fbytes));
     CK(hipMemset(c->fieldbase[n], 0, fbytes));
   }
-  CK(hipMalloc(&c->d_energy, 2 * sizeof(double)));
+  CK(hipMalloc(&c->d_energy, (2 + 2 * ENERGY_BLOCKS + 1) * sizeof(double)));
+  CK(hipMemset(c->d_energy, 0, (2 + 2 * ENERGY_BLOCKS + 1) * sizeof(double)));
   CK(hipMalloc(&c->d_probe, sizeof(DevProbe) * FDTD_MAX_PROBES));
   CK(hipMalloc(&c->d_box, sizeof(DevBox) * FDTD_MAX_BOXES));
   CK(hipMalloc(&c->lut, 256 * sizeof(float2)));
@@ -185,6 +186,11 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   if (const char* v = getenv("FDTD_WAVEFRONT")) c->wf_mode = atoi(v) ? 1 : 0;
   if (const char* v = getenv("FDTD_WF_LAG")) c->wf_lag = std::max(0, std::min(4096, atoi(v)));
   if (const char* v = getenv("FDTD_OCC_H")) c->occ_h = std::max(0, std::min(16, atoi(v)));
+  if (const char* v = getenv("FDTD_WF_FAULT_STEP")) c->wf_fault_step = atoll(v);   // test hook: the H blocks of that step wait for flags nobody sets (bounded wait -> error word)
+  if (const char* v = getenv("FDTD_XCD_BALANCE")) c->xcd_balance = atoi(v) != 0;        // experiments: 0 = XCD shares of equal length
+  if (const char* v = getenv("FDTD_XCD_WY")) c->xw_y = std::max(0.0, std::min(4.0, atof(v)));
+  if (const char* v = getenv("FDTD_XCD_WZ")) c->xw_z = std::max(0.0, std::min(4.0, atof(v)));
+  if (const char* v = getenv("FDTD_XCD_WYZ")) c->xw_yz = std::max(0.0, std::min(4.0, atof(v)));
   p.src_rng = nullptr; p.src_ids = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
   p.sig = c->sig; p.nsig = 0;
   p.probes = c->d_probe; p.nprobe = 0; p.max_steps = d->max_steps;
@@ -388,6 +394,7 @@ int fdtd_set_cpml(fdtd_ctx* c, const int32_t* sx, const int32_t* sy, const int32
         (eh ? c->p.psiH : c->p.psiE)[comp][w] = ptr;
       }
   c->have_cpml = (nsx + nsy + nsz) > 0;
+  xcd_shares_reset(c);   // the layers decide what a block costs
   return FDTD_OK;
 }
 
@@ -742,7 +749,7 @@ static int phase_E(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
   // single slab with Mur faces and fused sources: the post pass rides in the update_E launch (E+post, apply, H+pre: three
   // launches per timestep instead of four — on the reference's default 56x55x50 scene every launch is a ~4 us latency floor)
   c->mur_post_in_E = fused && c->any_mur && !multi && c->d_mur != nullptr && c->mur_fuse_post &&
-                     c->d.nx >= 5 && c->d.ny >= 5 && c->d.nz >= 5;
+                     c->d.nx >= 6 && c->d.ny >= 5 && c->d.nz >= 5;   // (nx = 5: both inner x nodes, 1 and 3, sit in ONE thread's four cells, and MurVals holds one x pair)
   launch_update_E(c, split ? 1 : 0, nk, step, fused, true, s);
   c->kev0 = c->kev1 = nullptr;
   if (split) {
@@ -795,7 +802,8 @@ static int p2p_check(fdtd_ctx* c);
 // whose fields do not fit the 256 MiB Infinity Cache (there the H sweep finds what the E sweep just touched in that cache
 // instead of in HBM); FDTD_FLAG_KERNEL_WAVEFRONT / $FDTD_WAVEFRONT=1 force it, FDTD_FLAG_KERNEL_DIRECT / =0 forbid it.
 static bool wavefront_possible(const fdtd_ctx* c) {
-  return (c->d.world == 1 || c->p.p2p) && !c->any_mur && c->d.nk >= 2;
+  // (an H block polls at most 64 flags with one wave: 2 * (1 + P4 / 256) + 3 <= 64, i.e. rows of at most 30 720 cells)
+  return (c->d.world == 1 || c->p.p2p) && !c->any_mur && c->d.nk >= 2 && 2 * (1 + c->p.P4 / FDTD_BLOCK) + 3 <= 64;
 }
 static bool wavefront_active(const fdtd_ctx* c) {
   const unsigned sel = c->d.flags & FDTD_FLAG_KERNEL_MASK;
@@ -840,7 +848,7 @@ static int wf_check(fdtd_ctx* c) {
   HIPCK(c, hipMemcpy(&e, c->wf_err, sizeof(int), hipMemcpyDeviceToHost));
   if (e) {
     hipMemset(c->wf_err, 0, sizeof(int));
-    return fdtd_fail(c, FDTD_E_DEVICE, "wavefront schedule: a block waited more than 2 s for the flag of an earlier block (dispatch not in order?); results of this run are invalid — select FDTD_FLAG_KERNEL_DIRECT");
+    return fdtd_fail(c, FDTD_E_DEVICE, "wavefront schedule: a block waited more than %.3g s for the flag of an earlier block (dispatch not in order?); the fields of this run are invalid — re-initialise them and select FDTD_FLAG_KERNEL_DIRECT (simulation.Simulation.run does both by itself)", (double)c->p.wf_limit * 1e-8);
   }
   return FDTD_OK;
 }
@@ -850,7 +858,7 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   if (sel > FDTD_FLAG_KERNEL_DIRECT && sel != FDTD_FLAG_KERNEL_WAVEFRONT)
     return fdtd_fail(c, FDTD_E_UNSUPPORTED, "kernel selection %u: the one-pass variants were removed (measured slower than the two-pass kernels on every workload)", sel);
   if (sel == FDTD_FLAG_KERNEL_WAVEFRONT && !wavefront_possible(c))
-    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "wavefront schedule: single slab or slabs on the p2p mailbox transport, no Mur faces, at least 2 planes");
+    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "wavefront schedule: single slab or slabs on the p2p mailbox transport, no Mur faces, at least 2 planes, rows of at most %d cells", 30 * FDTD_BLOCK * 4);
   if (c->p.p2p) return step_loop_p2p(c, nsteps, pe);
   const bool multi = c->d.world > 1;
   if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_p2p_attach (mailbox transport), fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
@@ -1069,7 +1077,7 @@ int fdtd_halo_put(fdtd_ctx* c, int which, const float* buf) {
 // control words: [4] error word (the rest is unused since the granule protocol: no flags, no arrival counters).
 __global__ void k_wallclock(unsigned long long* out) { *out = (unsigned long long)wall_clock64(); }
 
-struct P2pBlob { hipIpcMemHandle_t h; uint64_t bytes; uint64_t raw; int32_t pid, device, nx, ny; };
+struct P2pBlob { hipIpcMemHandle_t h; uint64_t bytes; uint64_t raw; int32_t pid, device, nx, ny; char busid[16]; };
 static_assert(sizeof(P2pBlob) <= 128, "blob must fit the 128-byte exchange buffer");
 
 static size_t p2p_floats(const fdtd_ctx* c) { return (size_t)16 * c->plane; }
@@ -1082,6 +1090,7 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_zero(float* mbox, const size
   if (ctl && t < (size_t)nctl) __hip_atomic_store(ctl + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+__global__ void k_p2p_clear_err(int* err) { __hip_atomic_store(err, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // zero the halo planes (and, with `ctl`, the 64 control words) of this context's own mailbox, on its stream
 static void p2p_zero(fdtd_ctx* c, bool ctl) {
   const size_t n4 = p2p_floats(c) / 4;      // 16-byte groups of the halo part
@@ -1122,15 +1131,40 @@ int fdtd_p2p_export(fdtd_ctx* c, void* out128) {
   HIPCK(c, hipIpcGetMemHandle(&b.h, c->mbox));
   b.bytes = c->mbox_bytes; b.raw = (uint64_t)(uintptr_t)c->mbox; b.pid = (int32_t)getpid(); b.device = c->d.device;
   b.nx = c->d.nx; b.ny = c->d.ny;
+  if (hipDeviceGetPCIBusId(b.busid, (int)sizeof b.busid, c->d.device) != hipSuccess) { (void)hipGetLastError(); b.busid[0] = 0; }
+  b.busid[sizeof b.busid - 1] = 0;
   memset(out128, 0, 128);
   memcpy(out128, &b, sizeof(b));
   return FDTD_OK;
 }
 
-static int p2p_open(fdtd_ctx* c, const void* blob128, void** out, bool* ipc) {
+// what the runtime knows about the way from this context's GPU to the GPU a neighbour's mailbox lives on (fdtd_p2p_link_info)
+static void p2p_note_link(fdtd_ctx* c, int which, const P2pBlob& b, bool ipc) {
+  int32_t* info = c->link_info[which];
+  for (int q = 0; q < 8; ++q) info[q] = -1;
+  info[1] = ipc ? 2 : 1;
+  int nb = -1;
+  if (!ipc) nb = b.device;                                   // same process: same ordinals
+  else if (b.busid[0] && hipDeviceGetByPCIBusId(&nb, b.busid) != hipSuccess) { (void)hipGetLastError(); nb = -1; }
+  info[0] = nb >= 0 ? nb : -2;
+  if (nb < 0) return;
+  info[7] = nb == c->d.device ? 1 : 0;
+  if (nb == c->d.device) { info[3] = 0; return; }
+  uint32_t type = 0, hops = 0;
+  if (hipExtGetLinkTypeAndHopCount(c->d.device, nb, &type, &hops) == hipSuccess) { info[2] = (int32_t)type; info[3] = (int32_t)hops; }
+  int v = 0;
+  if (hipDeviceGetP2PAttribute(&v, hipDevP2PAttrPerformanceRank, c->d.device, nb) == hipSuccess) info[4] = v;
+  if (hipDeviceGetP2PAttribute(&v, hipDevP2PAttrAccessSupported, c->d.device, nb) == hipSuccess) info[5] = v;
+  if (hipDeviceGetP2PAttribute(&v, hipDevP2PAttrNativeAtomicSupported, c->d.device, nb) == hipSuccess) info[6] = v;
+  (void)hipGetLastError();
+}
+
+static int p2p_open(fdtd_ctx* c, int which, const void* blob128, void** out, bool* ipc) {
   P2pBlob b;
   memcpy(&b, blob128, sizeof(b));
+  b.busid[sizeof b.busid - 1] = 0;
   if (b.nx != c->d.nx || b.ny != c->d.ny || b.bytes != c->mbox_bytes) return fdtd_fail(c, FDTD_E_ARG, "p2p: neighbour mailbox belongs to another grid");
+  p2p_note_link(c, which, b, b.pid != (int32_t)getpid());
   if (b.pid == (int32_t)getpid()) {   // same process: the pointer itself — on another device only through peer access
     if (b.device != c->d.device) {
       int can = 0;
@@ -1161,7 +1195,12 @@ static int p2p_open(fdtd_ctx* c, const void* blob128, void** out, bool* ipc) {
 int fdtd_p2p_attach(fdtd_ctx* c, const void* lower128, const void* upper128) {
   if (!c) return FDTD_E_ARG;
   if (c->d.world < 2) return fdtd_fail(c, FDTD_E_ARG, "p2p transport needs world > 1");
-  if ((c->d.rank > 0) != (lower128 != nullptr) || (c->d.rank < c->d.world - 1) != (upper128 != nullptr))
+  // FDTD_FLAG_LOOPBACK: a slab timed alone on one GPU — both blobs are its own; it pulls what a slab in its place pulls and
+  // pushes both halo planes into its own mailbox (include/fdtd_hip.h)
+  const bool echo = (c->d.flags & FDTD_FLAG_LOOPBACK) != 0;
+  if (echo && (!lower128 || !upper128 || memcmp(lower128, upper128, 128) != 0))
+    return fdtd_fail(c, FDTD_E_ARG, "p2p loopback: pass this context's own blob for both neighbours");
+  if (!echo && ((c->d.rank > 0) != (lower128 != nullptr) || (c->d.rank < c->d.world - 1) != (upper128 != nullptr)))
     return fdtd_fail(c, FDTD_E_ARG, "p2p: rank %d of %d needs exactly its existing neighbours' blobs", c->d.rank, c->d.world);
   if (c->comm || c->link_lo || c->link_hi) return fdtd_fail(c, FDTD_E_STATE, "p2p: another halo transport is already attached");
   // the mailbox flags count steps from zero (a kernel waits for flag >= step): a context that has already stepped
@@ -1170,13 +1209,13 @@ int fdtd_p2p_attach(fdtd_ctx* c, const void* lower128, const void* upper128) {
   int r = p2p_alloc(c);
   if (r) return r;
   HIPCK(c, hipSetDevice(c->d.device));
-  if (lower128 && (r = p2p_open(c, lower128, &c->peer_lo, &c->peer_lo_ipc))) return r;
-  if (upper128 && (r = p2p_open(c, upper128, &c->peer_hi, &c->peer_hi_ipc))) return r;
+  if (lower128 && (r = p2p_open(c, 0, lower128, &c->peer_lo, &c->peer_lo_ipc))) return r;
+  if (upper128 && (r = p2p_open(c, 1, upper128, &c->peer_hi, &c->peer_hi_ipc))) return r;
   float *in_E, *in_H; unsigned* ctl;
   p2p_views(c, c->mbox, &in_E, &in_H, &ctl);
   DevParams& p = c->p;
-  p.mb_in_E = upper128 ? in_E : nullptr;
-  p.mb_in_H = lower128 ? in_H : nullptr;
+  p.mb_in_E = c->d.rank < c->d.world - 1 ? in_E : nullptr;
+  p.mb_in_H = c->d.rank > 0 ? in_H : nullptr;
   p.p2p_err = (int*)(ctl + 4);
   p.mb_out_E = nullptr; p.mb_out_H = nullptr;
   if (c->peer_lo) { float *e, *h; unsigned* f; p2p_views(c, c->peer_lo, &e, &h, &f); p.mb_out_E = e; }
@@ -1291,6 +1330,7 @@ int fdtd_p2p_detach(fdtd_ctx* c) {
   if (c->peer_lo && c->peer_lo_ipc) hipIpcCloseMemHandle(c->peer_lo);
   if (c->peer_hi && c->peer_hi_ipc) hipIpcCloseMemHandle(c->peer_hi);
   c->peer_lo = c->peer_hi = nullptr; c->peer_lo_ipc = c->peer_hi_ipc = false;
+  for (int w = 0; w < 2; ++w) for (int q = 0; q < 8; ++q) c->link_info[w][q] = -1;
   DevParams& p = c->p;
   p.p2p = 0; p.mb_in_E = p.mb_in_H = p.mb_out_E = p.mb_out_H = nullptr;
   if (c->mbox) { p2p_zero(c, true); HIPCK(c, hipStreamSynchronize(c->stream)); }
@@ -1300,7 +1340,35 @@ int fdtd_p2p_detach(fdtd_ctx* c) {
 static int p2p_check(fdtd_ctx* c) {
   int err = 0;
   HIPCK(c, hipMemcpy(&err, c->p.p2p_err, sizeof(int), hipMemcpyDeviceToHost));
-  if (err) return fdtd_fail(c, FDTD_E_DEVICE, "p2p: a halo wait timed out (neighbour rank not stepping, or peer memory not visible)");
+  if (err) {
+    // reported once: cleared (with a system-scope store, like every access to the mailbox) so that a later run on this
+    // context is judged on its own — the fields of THIS run are invalid
+    hipLaunchKernelGGL(k_p2p_clear_err, dim3(1), dim3(1), 0, c->stream, c->p.p2p_err);
+    hipStreamSynchronize(c->stream);
+    return fdtd_fail(c, FDTD_E_DEVICE, "p2p: a halo wait timed out (neighbour rank not stepping, or peer memory not visible); the fields of this run are invalid");
+  }
+  return FDTD_OK;
+}
+
+int fdtd_p2p_link_info(fdtd_ctx* c, int which, int32_t info[8]) {
+  if (!c || !info || (which != 0 && which != 1)) return fdtd_fail(c, FDTD_E_ARG, "bad link query");
+  const bool attached = which == 0 ? c->peer_lo != nullptr : c->peer_hi != nullptr;
+  for (int q = 0; q < 8; ++q) info[q] = attached ? c->link_info[which][q] : -1;
+  return FDTD_OK;
+}
+
+int fdtd_schedule_info(fdtd_ctx* c, int32_t info[8]) {
+  if (!c || !info) return fdtd_fail(c, FDTD_E_ARG, "null argument");
+  for (int q = 0; q < 8; ++q) info[q] = 0;
+  const bool multi = c->d.world > 1;
+  const bool steppable = c->have_op && (!multi || c->p.p2p || c->comm || c->link_lo || c->link_hi);
+  const bool wf = steppable && wavefront_active(c);
+  info[0] = !steppable ? 0 : wf ? 1 : !c->any_mur ? 2 : (sources_fusable(c) && !multi && c->mur_fuse_post) ? 3 : 5;
+  info[1] = wf ? wf_lag_for(c) : 0;
+  info[2] = c->p.tys;
+  info[3] = c->d.nk * c->p.nstrips * c->p.nbs;
+  info[4] = !multi ? 0 : c->p.p2p ? 1 : c->comm ? 2 : (c->link_lo || c->link_hi) ? 3 : 4;
+  info[5] = (c->xcd_balance && c->have_cpml) ? 1 : 0;
   return FDTD_OK;
 }
 
@@ -1344,22 +1412,23 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
   if (ctxs[0]->p.p2p) {   // mailbox transport between contexts of this process: interleave the ranks' launches
     for (int r = 0; r < n; ++r) if (!ctxs[r]->p.p2p || ctxs[r]->any_mur) return fdtd_fail(ctxs[r], FDTD_E_STATE, "fdtd_run_linked: every context must use the p2p transport (no Mur)");
     for (int r = 0; r < n; ++r) p2p_prime_if_needed(ctxs[r]);   // every rank's initial halo is on its way before any rank's first launch
-    const bool wf = wavefront_active(ctxs[0]);
-    for (int r = 1; r < n; ++r) if (wavefront_active(ctxs[r]) != wf) return fdtd_fail(ctxs[r], FDTD_E_STATE, "fdtd_run_linked: the contexts disagree on the kernel schedule (set fdtd_desc.flags alike)");
+    // Slabs of different size may step under different schedules (AUTO: one launch per timestep only above a block count).
+    // Submission order of a timestep, TOP rank first: the one launch of a one-launch slab / the E launch of a two-launch
+    // slab; then, bottom-up, the H launches of the two-launch slabs.  Streams of one process may share a hardware queue,
+    // where a launch waits for the one submitted before it, so whatever a launch waits for on the device must have been
+    // submitted EARLIER: H of a slab's top plane (inside its one launch, or its H launch) needs the E blocks of plane 0 of
+    // the rank above for the SAME step — submitted before it in the first pass; E of plane 0 needs the H halo of the rank
+    // below of the PREVIOUS step.  (Bottom rank first timed out in exactly that way.)
+    std::vector<char> wf((size_t)n);
+    for (int r = 0; r < n; ++r) wf[r] = wavefront_active(ctxs[r]) ? 1 : 0;
     for (int s = 0; s < nsteps; ++s) {
       int rc;
-      if (wf) {   // one launch per timestep and slab, TOP rank first: a slab's launch waits (H of its top plane) for the E
-        // blocks of plane 0 in the launch of the rank above for the SAME step.  Streams of one process may share a hardware
-        // queue, where a launch waits for the one submitted before it: the launch waited for must be the earlier one
-        // (bottom rank first timed out in exactly that way).  What a launch needs from the rank below belongs to the previous step.
-        for (int r = n - 1; r >= 0; --r) { if ((rc = step_loop_wf(ctxs[r], 1, nullptr))) return rc; }
-        continue;
-      }
-      for (int r = 0; r < n; ++r) if ((rc = p2p_enqueue_E(ctxs[r], nullptr, 0))) return rc;
-      for (int r = 0; r < n; ++r) { if ((rc = p2p_enqueue_H(ctxs[r], nullptr, 0))) return rc; ctxs[r]->step++; }
+      for (int r = n - 1; r >= 0; --r) { if ((rc = wf[r] ? step_loop_wf(ctxs[r], 1, nullptr) : p2p_enqueue_E(ctxs[r], nullptr, 0))) return rc; }
+      for (int r = 0; r < n; ++r) if (!wf[r]) { if ((rc = p2p_enqueue_H(ctxs[r], nullptr, 0))) return rc; ctxs[r]->step++; }
     }
-    for (int r = 0; r < n && !wf; ++r) {
+    for (int r = 0; r < n; ++r) {
       fdtd_ctx* c = ctxs[r];
+      if (wf[r]) continue;
       HIPCK(c, hipSetDevice(c->d.device));
       if (nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);
     }

@@ -7,13 +7,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fdtd_hip.h"
 
 #define FDTD_MAX_PROBES 64
 #define FDTD_MAX_BOXES 64
+#define ENERGY_BLOCKS 1024      // blocks of k_energy (per-block partials, added in block order by the last block to finish)
 #ifndef FDTD_BLOCK
 #define FDTD_BLOCK 256
 #endif
@@ -80,6 +83,11 @@ struct DevParams {
   int tys, nbs, nstrips;
   FastDiv fd_nbs, fd_P4;     // dividers for the block / thread decode
   int sweep_rev;             // 1: update_H walks the blocks backwards (cache-friendly alternation with update_E)
+  // XCD shares of THIS launch (set by the launcher): XCD x sweeps blocks [xs[x], xs[x+1]) of the strip-major order, ranges of
+  // equal COST (CPML rows / planes weigh more: xcd_shares, kernels.hip); xgrid = 8 * the largest share = block positions of the
+  // main part.  ps / pm: the same for the blocks of ONE plane (k_step beyond the Infinity Cache: plane groups)
+  unsigned xs[9], xgrid;
+  unsigned ps[9], pm;
   // P2P mailbox halo transport (in-kernel pushes over xGMI / peer mappings; no streams, events or RCCL in the step loop).
   // Mailbox layout (one allocation per context, zero at start): [E: 2 parities][2 comps][2 * plane] words — 8-byte granules
   // {value, tag} — then the same for H, then 64 control words.  mb_in_*: my own mailbox; mb_out_*: the neighbour's (peer
@@ -92,6 +100,7 @@ struct DevParams {
   unsigned long long p2p_limit;   // wall-clock ticks a halo wait may last (10 s)
   // one launch per timestep (k_step): per-block completion flags of the E blocks [nk][nstrips][nbs], error word, wait limit
   unsigned* wf_flags; int* wf_err; unsigned long long wf_limit;
+  unsigned wf_wait_bias;     // added to the flag value the H blocks wait for: 0, except under the fault-injection test hook
   // ... and the probes of a step as the LAST blocks of its launch: H blocks of strip-planes that hold I-probe cells store
   // write-through and publish flags of their own (wf_flagsH, same indexing); probe q waits for the blocks wf_prb_blk[wf_prb_rng[q]]
   unsigned* wf_flagsH; const int* wf_prb_sp; const int* wf_prb_blk; const int2* wf_prb_rng;
@@ -124,17 +133,25 @@ struct fdtd_ctx {
   bool mbox_fine = false;                          // fine-grained (system-coherent) device memory
   void* peer_lo = nullptr; void* peer_hi = nullptr; // neighbours' mailboxes (IPC mappings or in-process pointers)
   bool peer_lo_ipc = false, peer_hi_ipc = false;
+  int32_t link_info[2][8] = {{-1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1}};   // fdtd_p2p_link_info, [lower / upper]
   bool p2p_primed = false;       // the initial top-plane Ix, Iy have been pushed to the upper rank (k_p2p_prime)
   // one launch per timestep (wavefront schedule, k_step)
   int wf_mode = -1;              // -1 auto (grids beyond the Infinity Cache), 0 off, 1 on; $FDTD_WAVEFRONT
   int wf_lag = 0;                // planes the E sweep runs ahead (0: auto); $FDTD_WF_LAG
   unsigned* wf_flags = nullptr; size_t wf_nflags = 0; int* wf_err = nullptr;
   unsigned wf_epoch = 0;         // flag value of the last wavefront launch
+  long long wf_fault_step = -1;  // test hook ($FDTD_WF_FAULT_STEP): at that step the H blocks wait for a flag value nobody publishes
   unsigned* wf_flagsH = nullptr; int* wf_prb_sp = nullptr; int* wf_prb_blk = nullptr; int2* wf_prb_rng = nullptr;
   bool wf_prb_dirty = true;      // probe tables of the wavefront launch need rebuilding (a probe was added)
   std::vector<int> h_prb_off[FDTD_MAX_PROBES];   // local offsets of every probe's cells (host copy)
   int occ_wf = 0;                // cap on resident blocks per CU of k_step (0: none); $FDTD_OCC_WF
   int occ_e = 0, occ_h = 0;      // cap on resident blocks per CU of update_E / update_H (0: none); $FDTD_OCC_E / $FDTD_OCC_H
+  // cost-weighted XCD shares (xcd_shares): relative extra cost of a thread in a y-layer row / in a z-layer plane / in both,
+  // over a thread outside the layers; $FDTD_XCD_WY / _WZ / _WYZ, $FDTD_XCD_BALANCE=0 for equal lengths
+  bool xcd_balance = true;
+  double xw_y = 0.45, xw_z = 0.45, xw_yz = 0.35;
+  struct XcdShare { unsigned xs[9]; unsigned grid; };
+  std::map<std::pair<int, int>, XcdShare> xcd_cache;   // (first plane, planes) of a launch -> its shares
   float *vv = nullptr, *vi = nullptr, *ii = nullptr, *iv = nullptr;
   uint8_t* ecls = nullptr;
   float2* lut = nullptr;
@@ -207,3 +224,4 @@ void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);   // runn
 void launch_rec_dft(const float* rec, long npts, int ns, int nfreq, const double* d_tw, double* d_out, hipStream_t s);
 void launch_energy(fdtd_ctx* c, hipStream_t s);
 void choose_tiling(fdtd_ctx* c);
+void xcd_shares_reset(fdtd_ctx* c);   // after the CPML layers or the tiling changed

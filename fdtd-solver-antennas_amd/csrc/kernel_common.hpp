@@ -39,32 +39,34 @@ __device__ __forceinline__ float4 sub4(const float4& a, const float4& b) {
   return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
 }
 
-// XCD-aware, strip-major block decode: block-uniform part (strip, plane, block within the strip-plane) ...
-__device__ __forceinline__ void decode_block(int nbs, int nkr, int extra, int& strip, int& kk, int& pb) {
-  const unsigned nb = gridDim.x - (unsigned)extra, b = blockIdx.x;
-  const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
-  const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-  const unsigned per_strip = (unsigned)nkr * (unsigned)nbs;
-  const unsigned s = v / per_strip;
-  const unsigned rem = v - s * per_strip;
-  const unsigned k = rem / (unsigned)nbs;
-  strip = (int)s; kk = (int)k; pb = (int)(rem - k * (unsigned)nbs);
-}
+// XCD-aware, strip-major block decode.  Block index = 8 * position + XCD (workgroups go round-robin to the eight XCDs, each
+// with its own 4 MiB L2); XCD x sweeps the contiguous range [xs[x], xs[x+1]) of the strip-major block order, so that the
+// k+-1 and j+-1 neighbour rows are hits in ITS L2.  The ranges are equal in COST, not in length (xcd_shares, kernels.hip):
+// blocks of CPML planes / rows move 40-50 % more bytes, and the XCDs do not help each other out — with equal lengths the XCDs
+// that own the y-layer strips (the first and the last) and, on short grids, the z-layer planes finish last and everybody
+// else idles.  Positions beyond an XCD's share are empty blocks at the END of the dispatch order: they return at once.
 __device__ __forceinline__ unsigned fd_div(const unsigned n, const FastDiv& f) { return f.d == 1u ? n : __umulhi(n, f.mul) >> f.shr; }
-// the same decode with the three divisions replaced by multiply-high (two-pass kernels)
-// rev: this XCD walks its range backwards.  update_E sweeps forwards and update_H backwards, so each half-step starts
-// on the data the previous one touched last (still in this XCD's L2 / the Infinity Cache) instead of on the data it
-// touched first (evicted by then on grids larger than the caches).
-__device__ __forceinline__ void decode_block_fd(const FastDiv& fd_ps, const FastDiv& fd_nbs, int extra, int rev, int& strip, int& kk, int& pb) {
-  const unsigned nb = gridDim.x - (unsigned)extra, b = blockIdx.x;
-  const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u;
-  unsigned pos = b >> 3;
-  if (rev) pos = (xcd < r ? q : q - 1u) - pos;
-  const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+// bb: block index within the main part of the launch.  rev: this XCD walks its range backwards.  update_E sweeps forwards
+// and update_H backwards, so each half-step starts on the data the previous one touched last (still in this XCD's L2 / the
+// Infinity Cache) instead of on the data it touched first (evicted by then on grids larger than the caches).
+__device__ __forceinline__ bool xcd_position(const unsigned (&xs)[9], const unsigned bb, const int rev, unsigned& v) {
+  const unsigned xcd = bb & 7u;
+  unsigned pos = bb >> 3;
+  const unsigned first = xs[xcd], cnt = xs[xcd + 1] - first;
+  if (pos >= cnt) return false;
+  if (rev) pos = cnt - 1u - pos;
+  v = first + pos;
+  return true;
+}
+// strip-major order: v = (strip * planes + kk) * nbs + pb (fd_ps divides by planes * nbs)
+__device__ __forceinline__ bool decode_block_fd(const DevParams& p, const FastDiv& fd_ps, const FastDiv& fd_nbs, int rev, int& strip, int& kk, int& pb) {
+  unsigned v;
+  if (!xcd_position(p.xs, blockIdx.x, rev, v)) return false;
   const unsigned s = fd_div(v, fd_ps);
   const unsigned rem = v - s * fd_ps.d;
   const unsigned k = fd_div(rem, fd_nbs);
   strip = (int)s; kk = (int)k; pb = (int)(rem - k * fd_nbs.d);
+  return true;
 }
 // ---- P2P mailbox protocol -------------------------------------------------------------------------------------------
 // A halo value travels as an 8-byte GRANULE {value, tag}: tag = number of the timestep whose half-step produced it (+1 for E, +2 for
@@ -125,21 +127,13 @@ __device__ __forceinline__ void mb_pull2(const float* slot_a, const float* slot_
 // the neighbour's mailbox (fine-grained memory: a round trip of several microseconds) then run beside the other planes
 // instead of at the kernel's tail; a neighbour that is late makes these blocks load again while the rest proceeds.  With
 // dep_first = 0 they are the last ones (what the flag protocol of round 1 needed, when a wait could last a kernel).
-__device__ __forceinline__ void decode_block_p2p(const FastDiv& fd_ps, const FastDiv& fd_nbs, int extra, unsigned nb_main, int dep_plane,
+__device__ __forceinline__ bool decode_block_p2p(const DevParams& p, const FastDiv& fd_ps, const FastDiv& fd_nbs, unsigned nb_main, unsigned nb_dep, int dep_plane,
                                                  int main_first, int dep_first, int& strip, int& k, int& pb) {
-  const unsigned nb = gridDim.x - (unsigned)extra, b = blockIdx.x;
+  const unsigned b = blockIdx.x;
   unsigned v;
-  if (dep_first) {
-    const unsigned nb_dep = nb - nb_main;
-    if (b < nb_dep) v = nb_main + b;
-    else {
-      const unsigned bb = b - nb_dep, q = nb_main >> 3, r = nb_main & 7u, xcd = bb & 7u, pos = bb >> 3;
-      v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-    }
-  } else {
-    const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
-    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-  }
+  if (dep_first ? b < nb_dep : b >= p.xgrid) {           // a block of the halo plane
+    v = nb_main + (dep_first ? b : b - p.xgrid);
+  } else if (!xcd_position(p.xs, dep_first ? b - nb_dep : b, 0, v)) return false;
   if (v < nb_main) {
     const unsigned s = fd_div(v, fd_ps);
     const unsigned rem = v - s * fd_ps.d;
@@ -150,6 +144,7 @@ __device__ __forceinline__ void decode_block_p2p(const FastDiv& fd_ps, const Fas
     const unsigned s = fd_div(w, fd_nbs);
     strip = (int)s; k = dep_plane; pb = (int)(w - s * fd_nbs.d);
   }
+  return true;
 }
 
 // ---- one launch per timestep (k_step): device-scope accesses and the per-block flags ------------------------------------

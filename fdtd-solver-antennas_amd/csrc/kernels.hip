@@ -262,10 +262,10 @@ __global__ __launch_bounds__(FDTD_BLOCK, (PML || (COEF == 0 && P2P)) ? FDTD_E_MI
     return;
   }
   int strip, kk, pb, k;
-  if (P2P) {   // all planes in one launch, the halo-dependent bottom plane last
-    decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, 0, 1, p.p2p_dep_first, strip, k, pb);
+  if (P2P) {   // all planes in one launch, the halo-dependent bottom plane first (or last) in dispatch order
+    if (!decode_block_p2p(p, fd_ps, p.fd_nbs, nb_main, (unsigned)(p.nstrips * p.nbs), 0, 1, p.p2p_dep_first, strip, k, pb)) return;
   } else {
-    decode_block_fd(fd_ps, p.fd_nbs, extra, 0, strip, kk, pb);
+    if (!decode_block_fd(p, fd_ps, p.fd_nbs, 0, strip, kk, pb)) return;
     k = k_begin + kk;
   }
   body_E<COEF, PML, FUSE, P2P, false>(p, strip, k, pb, step, s_lut, s_psi, s_xc, s_src, 0u);
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, 4) void k_update_E_mur(const DevParams 
     return;
   }
   int strip, kk, pb;
-  decode_block_fd(fd_ps, p.fd_nbs, extra, 0, strip, kk, pb);
+  if (!decode_block_fd(p, fd_ps, p.fd_nbs, 0, strip, kk, pb)) return;
   body_E<COEF, PML, true, false, false, true>(p, strip, k_begin + kk, pb, step, s_lut, s_psi, s_xc, s_src, 0u, &m);
 }
 
@@ -345,7 +345,7 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
     ix = ldo4(p.I[0], uo); iy = ldo4(p.I[1], uo); iz = ldo4(p.I[2], uo);
     if (staged)
       psi_stage_issue(p, p.psiH, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
-    wf_wait(p, k, strip, pb, wf_target);
+    wf_wait(p, k, strip, pb, wf_target + p.wf_wait_bias);
     const DevRsrc b0 = dev_buf(p.V[0]), b1 = dev_buf(p.V[1]), b2 = dev_buf(p.V[2]);
     const unsigned bo = uo << 2;
     vx = ldb4_dev(b0, bo, 0u); vy = ldb4_dev(b1, bo, 0u); vz = ldb4_dev(b2, bo, 0u);
@@ -443,10 +443,10 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
     return;
   }
   int strip, kk, pb, k;
-  if (P2P) {   // all planes in one launch, the halo-dependent top plane last
-    decode_block_p2p(fd_ps, p.fd_nbs, extra, nb_main, p.nk - 1, 0, p.p2p_dep_first, strip, k, pb);
+  if (P2P) {   // all planes in one launch, the halo-dependent top plane first (or last) in dispatch order
+    if (!decode_block_p2p(p, fd_ps, p.fd_nbs, nb_main, (unsigned)(p.nstrips * p.nbs), p.nk - 1, 0, p.p2p_dep_first, strip, k, pb)) return;
   } else {
-    decode_block_fd(fd_ps, p.fd_nbs, extra, p.sweep_rev, strip, kk, pb);
+    if (!decode_block_fd(p, fd_ps, p.fd_nbs, p.sweep_rev, strip, kk, pb)) return;
     k = k_begin + kk;
   }
   body_H<RAW, PML, P2P, false>(p, strip, k, pb, step, s_psi, s_xc, 0u);
@@ -487,13 +487,10 @@ __global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_M
     // Cache-resident slab: ALL E blocks, then ALL H blocks, each half in the two-launch kernels' own order (XCD-contiguous,
     // strip-major; fd_2m is the divider nk * nbs here; odd steps walk every XCD's range backwards).  No empty positions: on
     // planes of a few dozen blocks the plane-group order below dispatches more empty blocks than real ones.
-    const unsigned nE = nmain >> 1;
+    const unsigned nE = nmain >> 1;   // = p.xgrid: eight cost-weighted XCD shares, padded to the largest
     is_h = b >= nE;
-    const unsigned bb = is_h ? b - nE : b;
-    const unsigned q = nE >> 3, r = nE & 7u, xcd = bb & 7u;
-    unsigned ps = bb >> 3;
-    if (down) ps = (xcd < r ? q : q - 1u) - ps;
-    const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ps;
+    unsigned v;
+    if (!xcd_position(p.xs, is_h ? b - nE : b, down, v)) return;
     strip = fd_div(v, fd_2m);
     const unsigned rem = v - strip * fd_2m.d;
     const unsigned kk = fd_div(rem, p.fd_nbs);
@@ -504,9 +501,8 @@ __global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_M
     is_h = w >= m;
     const unsigned r = is_h ? w - m : w;
     k = is_h ? (int)grp - lag : (int)grp;
-    // this XCD group's contiguous share of the plane's nbp = nstrips * nbs blocks
-    const unsigned q = nbp >> 3, rem = nbp & 7u;
-    const unsigned cnt = q + (x < rem ? 1u : 0u), first = x * q + (x < rem ? x : rem);
+    // this XCD group's contiguous share of the plane's nbp = nstrips * nbs blocks (equal in cost: the y-layer strips count more)
+    const unsigned first = p.ps[x], cnt = p.ps[x + 1] - first;
     if (k < 0 || k >= p.nk || r >= cnt) return;
     // odd steps walk the planes downwards: a step starts on the planes the previous one touched last (still in the Infinity
     // Cache).  The flags an H block waits for — planes k and k + 1 — are earlier in dispatch order in either direction.
@@ -679,7 +675,9 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_rec_dft(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // K8: energy sums over the owned planes (pads are zero, ghosts excluded).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(FDTD_BLOCK) void k_energy(const DevParams p, double* out) {
+// Every block leaves its two partial sums in part[2 * block]; the LAST block to arrive (a counter) adds them in block order:
+// the same bits whatever the arrival order — the end criterion of a run is reproducible (atomicAdd on doubles is not).
+__global__ __launch_bounds__(FDTD_BLOCK) void k_energy(const DevParams p, double* out, double* part, unsigned* arrived) {
   __shared__ double rv[FDTD_BLOCK], ri[FDTD_BLOCK];
   double sv = 0.0, si = 0.0;
   const int n4 = p.nloc / 4;
@@ -697,7 +695,27 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_energy(const DevParams p, double
     if ((int)threadIdx.x < w) { rv[threadIdx.x] += rv[threadIdx.x + w]; ri[threadIdx.x] += ri[threadIdx.x + w]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { atomicAdd(out, rv[0]); atomicAdd(out + 1, ri[0]); }
+  __shared__ unsigned last;
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = rv[0]; part[2 * blockIdx.x + 1] = ri[0];
+    __threadfence();   // the partials are visible device-wide before the arrival is counted
+    last = atomicAdd(arrived, 1u) == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double sv2 = 0.0, si2 = 0.0;   // fixed order: thread t takes blocks t, t + 256, ...; then the tree above
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += FDTD_BLOCK) {
+    sv2 += __hip_atomic_load(part + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    si2 += __hip_atomic_load(part + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  rv[threadIdx.x] = sv2; ri[threadIdx.x] = si2;
+  __syncthreads();
+  for (int w = FDTD_BLOCK / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { rv[threadIdx.x] += rv[threadIdx.x + w]; ri[threadIdx.x] += ri[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = rv[0]; out[1] = ri[0]; *arrived = 0u; }
 }
 
 }  // namespace
@@ -747,6 +765,104 @@ void choose_tiling(fdtd_ctx* c) {
   c->p.fd_P4 = make_fastdiv((unsigned)P4);
 }
 
+// ---- cost-weighted XCD shares ------------------------------------------------------------------------------------------
+// The launch's blocks in strip-major order, v = (strip * planes + kk) * nbs + pb, cut into eight contiguous ranges of equal
+// COST, one per XCD (kernel_common.hpp: xcd_position).  Cost of a block = its active threads, a thread in a y-layer row
+// counting 1 + w_y, in a z-layer plane 1 + w_z, in both 1 + w_y + w_z + w_yz (two more psi arrays read and written per
+// layer: +16 of 37 bytes per cell and half-step; where two layers meet the second pair is a direct load after the
+// differences).  Every block also pays a constant (dispatch, the LDS tables, the barrier).  The x layers touch every
+// wave alike and do not enter.
+static const double XCD_BLOCK_CONST = 0.06;   // of a full block's thread cost
+static void strip_block_costs(const fdtd_ctx* c, std::vector<double>& act, std::vector<double>& ylay) {
+  const DevParams& p = c->p;
+  act.assign((size_t)p.nstrips * p.nbs, 0.0);
+  ylay.assign((size_t)p.nstrips * p.nbs, 0.0);
+  for (int s = 0; s < p.nstrips; ++s) {
+    const int rows = std::min(p.tys, p.ny - s * p.tys);
+    for (int jj = 0; jj < rows; ++jj) {
+      const int j = s * p.tys + jj;
+      const bool yl = c->have_cpml && (j < p.pml_lo[1] || j >= p.pml_hi[1]);
+      // threads [jj * P4, (jj + 1) * P4) of the strip-plane, spread over the blocks they fall into
+      int t0 = jj * p.P4;
+      const int t1 = t0 + p.P4;
+      while (t0 < t1) {
+        const int pb = t0 / FDTD_BLOCK, upto = std::min(t1, (pb + 1) * FDTD_BLOCK);
+        act[(size_t)s * p.nbs + pb] += upto - t0;
+        if (yl) ylay[(size_t)s * p.nbs + pb] += upto - t0;
+        t0 = upto;
+      }
+    }
+  }
+}
+static void cut_shares(const std::vector<double>& cost, unsigned (&xs)[9], unsigned& grid) {
+  const size_t n = cost.size();
+  double total = 0.0;
+  for (double v : cost) total += v;
+  double run = 0.0;
+  size_t v = 0;
+  xs[0] = 0u;
+  for (int x = 1; x < 8; ++x) {
+    const double target = total * x / 8.0;
+    // the block that straddles the target goes to whichever side leaves the smaller error
+    while (v < n && run + cost[v] <= target) run += cost[v++];
+    if (v < n && target - run > run + cost[v] - target) run += cost[v++];
+    xs[x] = (unsigned)v;
+  }
+  xs[8] = (unsigned)n;
+  unsigned m = 0;
+  for (int x = 0; x < 8; ++x) m = std::max(m, xs[x + 1] - xs[x]);
+  grid = 8u * m;
+}
+static void equal_shares(unsigned n, unsigned (&xs)[9], unsigned& grid) {
+  const unsigned q = n >> 3, r = n & 7u;
+  for (unsigned x = 0; x <= 8; ++x) xs[x] = x * q + std::min(x, r);
+  grid = 8u * (q + (r ? 1u : 0u));
+}
+void xcd_shares_reset(fdtd_ctx* c) { c->xcd_cache.clear(); }
+// shares of a launch over planes [k_first, k_first + planes) -> c->p.xs / c->p.xgrid
+static void set_xcd_shares(fdtd_ctx* c, int k_first, int planes) {
+  DevParams& p = c->p;
+  const auto key = std::make_pair(k_first, planes);
+  auto it = c->xcd_cache.find(key);
+  if (it == c->xcd_cache.end()) {
+    fdtd_ctx::XcdShare sh{};
+    const unsigned n = (unsigned)p.nstrips * (unsigned)planes * (unsigned)p.nbs;
+    if (!c->xcd_balance || !c->have_cpml) equal_shares(n, sh.xs, sh.grid);
+    else {
+      std::vector<double> act, ylay, cost((size_t)n);
+      strip_block_costs(c, act, ylay);
+      for (int s = 0; s < p.nstrips; ++s)
+        for (int kk = 0; kk < planes; ++kk) {
+          const int k = k_first + kk;
+          const bool zl = k < p.pml_lo[2] || k >= p.pml_hi[2];
+          for (int pb = 0; pb < p.nbs; ++pb) {
+            const double a = act[(size_t)s * p.nbs + pb], y = ylay[(size_t)s * p.nbs + pb];
+            cost[((size_t)s * planes + kk) * p.nbs + pb] =
+                XCD_BLOCK_CONST * FDTD_BLOCK + a + c->xw_y * y + (zl ? c->xw_z * a + c->xw_yz * y : 0.0);
+          }
+        }
+      cut_shares(cost, sh.xs, sh.grid);
+    }
+    it = c->xcd_cache.emplace(key, sh).first;
+  }
+  for (int x = 0; x <= 8; ++x) p.xs[x] = it->second.xs[x];
+  p.xgrid = it->second.grid;
+}
+// shares of the blocks of ONE plane (k_step with H a few planes behind E: every XCD group takes its share of each plane) -> c->p.ps / pm
+static void set_plane_shares(fdtd_ctx* c) {
+  DevParams& p = c->p;
+  const unsigned nbp = (unsigned)p.nstrips * (unsigned)p.nbs;
+  unsigned grid;
+  if (!c->xcd_balance || !c->have_cpml) equal_shares(nbp, p.ps, grid);
+  else {
+    std::vector<double> act, ylay, cost((size_t)nbp);
+    strip_block_costs(c, act, ylay);
+    for (size_t q = 0; q < cost.size(); ++q) cost[q] = XCD_BLOCK_CONST * FDTD_BLOCK + act[q] + c->xw_y * ylay[q];
+    cut_shares(cost, p.ps, grid);
+  }
+  p.pm = grid / 8u;
+}
+
 // Occupancy cap without recompiling (experiments): dynamic LDS padding so that at most `cap` blocks fit the CU's
 // 160 KiB (0 = no cap).  Measured (profiles/r01/occupancy_cap_sweep.txt): throughput falls monotonically with the cap
 // on cache-resident and HBM-resident grids alike, so the default is no cap.
@@ -765,15 +881,19 @@ static void launch_main(fdtd_ctx* c, K kern, dim3 grid, unsigned lds, hipStream_
 }
 
 template <int COEF, bool PML>
-static void launch_E2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long step, bool fused, int extra, hipStream_t s) {
+static void launch_E2(fdtd_ctx* c, int k_begin, int nkr, long long step, bool fused, int extra, hipStream_t s) {
   const unsigned lut_bytes = (unsigned)(c->raw_op ? 0 : (c->p.lut_n + 1) / 2) * 16u;   // dynamic LDS: the coefficient table, whole 16-byte LDS-DMA pieces
   const unsigned pad = lut_bytes + lds_pad(c->occ_e, (PML && FDTD_PSI_STAGE ? 20480u : 4608u) + lut_bytes);
-  if (c->p.p2p) {   // whole slab in one launch, bottom plane last (decode_block_p2p)
+  if (c->p.p2p) {   // whole slab in one launch: [bottom plane (halo-dependent)] [planes 1.. in eight XCD shares] [probe block] (decode_block_p2p)
     const FastDiv fd_ps = make_fastdiv((unsigned)(nkr - 1) * (unsigned)c->p.nbs);
     const unsigned nb_main = (unsigned)c->p.nstrips * (unsigned)(nkr - 1) * (unsigned)c->p.nbs;
+    set_xcd_shares(c, 1, nkr - 1);
+    const dim3 grid(c->p.xgrid + (unsigned)(c->p.nstrips * c->p.nbs) + (unsigned)extra);
     launch_main(c, k_update_E<COEF, PML, true, true>, grid, pad, s, c->p, 0, fd_ps, step, extra, nb_main);
     return;
   }
+  set_xcd_shares(c, k_begin, nkr);
+  const dim3 grid(c->p.xgrid + (unsigned)extra);
   const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
   if (fused && c->mur_post_in_E) {
     launch_main(c, k_update_E_mur<COEF, PML>, grid, pad, s, c->p, k_begin, fd_ps, step, extra, c->h_mur);
@@ -787,28 +907,31 @@ void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool f
   const int nkr = k_end - k_begin;
   if (nkr <= 0) return;
   const int extra = (fused && probe_block) ? 1 : 0;
-  const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs + extra));
   const int coef = c->raw_op ? 0 : (c->packed_op ? 2 : 1);
   if (c->have_cpml) {
-    if (coef == 0) launch_E2<0, true>(c, grid, k_begin, nkr, step, fused, extra, s);
-    else if (coef == 1) launch_E2<1, true>(c, grid, k_begin, nkr, step, fused, extra, s);
-    else launch_E2<2, true>(c, grid, k_begin, nkr, step, fused, extra, s);
+    if (coef == 0) launch_E2<0, true>(c, k_begin, nkr, step, fused, extra, s);
+    else if (coef == 1) launch_E2<1, true>(c, k_begin, nkr, step, fused, extra, s);
+    else launch_E2<2, true>(c, k_begin, nkr, step, fused, extra, s);
   } else {
-    if (coef == 0) launch_E2<0, false>(c, grid, k_begin, nkr, step, fused, extra, s);
-    else if (coef == 1) launch_E2<1, false>(c, grid, k_begin, nkr, step, fused, extra, s);
-    else launch_E2<2, false>(c, grid, k_begin, nkr, step, fused, extra, s);
+    if (coef == 0) launch_E2<0, false>(c, k_begin, nkr, step, fused, extra, s);
+    else if (coef == 1) launch_E2<1, false>(c, k_begin, nkr, step, fused, extra, s);
+    else launch_E2<2, false>(c, k_begin, nkr, step, fused, extra, s);
   }
 }
 
 template <bool RAW, bool PML>
-static void launch_H2(fdtd_ctx* c, dim3 grid, int k_begin, int nkr, long long step, int extra, hipStream_t s) {
+static void launch_H2(fdtd_ctx* c, int k_begin, int nkr, long long step, int extra, hipStream_t s) {
   const unsigned pad = lds_pad(c->occ_h, PML && FDTD_PSI_STAGE ? 18432u : 2560u);
   if (c->p.p2p) {
     const FastDiv fd_ps = make_fastdiv((unsigned)(nkr - 1) * (unsigned)c->p.nbs);
     const unsigned nb_main = (unsigned)c->p.nstrips * (unsigned)(nkr - 1) * (unsigned)c->p.nbs;
+    set_xcd_shares(c, 0, nkr - 1);
+    const dim3 grid(c->p.xgrid + (unsigned)(c->p.nstrips * c->p.nbs) + (unsigned)extra);
     launch_main(c, k_update_H<RAW, PML, true>, grid, pad, s, c->p, 0, fd_ps, step, extra, nb_main);
     return;
   }
+  set_xcd_shares(c, k_begin, nkr);
+  const dim3 grid(c->p.xgrid + (unsigned)extra);
   const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
   launch_main(c, k_update_H<RAW, PML, false>, grid, pad, s, c->p, k_begin, fd_ps, step, extra, 0u);
 }
@@ -820,13 +943,12 @@ void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool p
   // blocks only ride along when the probe block does (the kernel tells them apart by their distance from the end)
   c->p.mur_nb = (mur_pre && probe_block && c->any_mur && c->d_mur) ? 12 * c->p.mur_nbx : 0;
   const int extra = (probe_block ? 1 : 0) + c->p.mur_nb;
-  const dim3 grid((unsigned)(c->p.nstrips * nkr * c->p.nbs + extra));
   if (c->raw_op) {
-    if (c->have_cpml) launch_H2<true, true>(c, grid, k_begin, nkr, step, extra, s);
-    else launch_H2<true, false>(c, grid, k_begin, nkr, step, extra, s);
+    if (c->have_cpml) launch_H2<true, true>(c, k_begin, nkr, step, extra, s);
+    else launch_H2<true, false>(c, k_begin, nkr, step, extra, s);
   } else {
-    if (c->have_cpml) launch_H2<false, true>(c, grid, k_begin, nkr, step, extra, s);
-    else launch_H2<false, false>(c, grid, k_begin, nkr, step, extra, s);
+    if (c->have_cpml) launch_H2<false, true>(c, k_begin, nkr, step, extra, s);
+    else launch_H2<false, false>(c, k_begin, nkr, step, extra, s);
   }
 }
 
@@ -848,16 +970,19 @@ int wf_lag_for(const fdtd_ctx* c) {
 
 template <int COEF, bool PML, bool P2P>
 static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s) {
-  const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs, m = (nbp + 7u) / 8u;
+  const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs;
   const unsigned lut_bytes = (unsigned)(c->raw_op ? 0 : (c->p.lut_n + 1) / 2) * 16u;
   const unsigned pad = lut_bytes + lds_pad(c->occ_wf, (PML && FDTD_PSI_STAGE ? 20480u : 2560u) + lut_bytes);
   const int down = (!P2P && c->p.sweep_rev && (step & 1)) ? 1 : 0;
-  if (lag >= c->p.nk) {   // all E blocks, then all H blocks (cache-resident slabs: wf_lag_for)
-    const unsigned nE = nbp * (unsigned)c->p.nk;
+  if (lag >= c->p.nk) {   // all E blocks, then all H blocks (cache-resident slabs: wf_lag_for), each half in eight cost-weighted XCD shares
+    set_xcd_shares(c, 0, c->p.nk);
+    const unsigned nE = c->p.xgrid;
     launch_main(c, k_step<COEF, PML, P2P>, dim3(2u * nE + (unsigned)c->nprobe), pad, s, c->p, step, -1, c->wf_epoch, nbp,
                 make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), down, 2u * nE);
     return;
   }
+  set_plane_shares(c);
+  const unsigned m = c->p.pm;   // positions per role in a plane group: the largest XCD share of a plane
   const unsigned nmain = 8u * 2u * m * (unsigned)(c->p.nk + lag);
   const dim3 grid(nmain + (unsigned)c->nprobe);
   launch_main(c, k_step<COEF, PML, P2P>, grid, pad, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m), down, nmain);
@@ -920,6 +1045,8 @@ int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s) {
   c->p.wf_flags = c->wf_flags; c->p.wf_err = c->wf_err;
   c->p.wf_flagsH = c->wf_flagsH; c->p.wf_prb_sp = c->wf_prb_sp; c->p.wf_prb_blk = c->wf_prb_blk; c->p.wf_prb_rng = c->wf_prb_rng;
   c->p.wf_limit = 200000000ull;   // 2 s of the 100 MHz wall clock
+  c->p.wf_wait_bias = 0u;
+  if (step == c->wf_fault_step) { c->p.wf_wait_bias = 1u; c->p.wf_limit = 2000ull; }   // test hook: a flag value nobody publishes, 20 us
   if (2 * (1 + c->p.P4 / FDTD_BLOCK) + 3 > 64) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "wavefront schedule: rows of more than %d cells", 30 * FDTD_BLOCK * 4);
   ++c->wf_epoch;
   const int lag = wf_lag_for(c);
@@ -1007,6 +1134,7 @@ void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_
 }
 
 void launch_energy(fdtd_ctx* c, hipStream_t s) {
-  hipMemsetAsync(c->d_energy, 0, 2 * sizeof(double), s);
-  hipLaunchKernelGGL(k_energy, dim3(1024), dim3(FDTD_BLOCK), 0, s, c->p, c->d_energy);
+  // d_energy: [0..1] the two sums, [2..2 + 2 * ENERGY_BLOCKS) per-block partials, then the arrival counter (zero between launches)
+  hipLaunchKernelGGL(k_energy, dim3(ENERGY_BLOCKS), dim3(FDTD_BLOCK), 0, s, c->p, c->d_energy, c->d_energy + 2,
+                     reinterpret_cast<unsigned*>(c->d_energy + 2 + 2 * ENERGY_BLOCKS));
 }

@@ -39,6 +39,7 @@ class SlabComm:
         self.rccl_error = None
         self.p2p_error = None
         self.ms_exchange = 0.0       # host transport: wall time spent in halo exchanges
+        self.ms_selftest = 0.0       # p2p transport: wall time of the data-path self-test over the neighbour links
 
     # -- tensors on the right device for the process group ------------------------------------------
     def _to_t(self, a: np.ndarray):
@@ -93,10 +94,13 @@ class SlabComm:
                         ok, self.p2p_error = False, str(exc)
                     if self._all_agree(ok):
                         self.dist.barrier()
+                        import time
+                        t0 = time.perf_counter()
                         try:                       # tokens across every neighbour link before a timestep depends on them
                             eng.p2p_selftest(0x5E1F0001)
                         except _capi.FdtdError as exc:
                             ok, self.p2p_error = False, str(exc)
+                        self.ms_selftest = (time.perf_counter() - t0) * 1e3
                     if self._all_agree(ok):
                         sim.external_transport = None
                         self.transport_used = "p2p"

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import json
 import os
+import shutil
 import time
 from typing import List, Optional, Sequence
 
@@ -204,8 +205,9 @@ class LumpedPort:
         ti = (np.arange(i.size) + 0.5) * dt
         self.u_data, self.i_data = UIData(tu, u), UIData(ti, i)
         if u.size == i.size and u.size > 1:
-            # one exponent matrix for both series: exp(-jw(t + dt/2)) = exp(-jwt) * exp(-jw dt/2)
-            ex = np.exp(-2j * np.pi * np.outer(self.freq, tu))
+            # one exponent matrix for both series: exp(-jw(t + dt/2)) = exp(-jwt) * exp(-jw dt/2) — and for every port of the
+            # run asked for the same frequencies (the multi-patch scenes have up to 16): kept on the FDTD object
+            ex = self._fdtd._port_exponents(self.freq, u.size, dt)
             scale = 2.0 * (dt if signal_type == "pulse" else 1.0 / u.size)
             self.uf_tot = (ex @ np.asarray(u, float)) * scale
             self.if_tot = (ex @ np.asarray(i, float)) * np.exp(-1j * np.pi * self.freq * dt) * scale
@@ -227,10 +229,29 @@ class nf2ff:
         self._fdtd, self.name = fdtd, name
         self.start, self.stop = start, stop
 
+    def can_evaluate(self, freq) -> bool:
+        """Whether CalcNF2FF can answer for `freq` after this run: any frequency inside the recorder's band when the faces
+        were recorded in the time domain (the default) or when the running DFT took the comb it snaps to; else only the
+        frequencies the running DFT accumulated."""
+        sim = self._fdtd.sim
+        if sim is None or sim.nf2ff_box is None:
+            return False
+        f = np.atleast_1d(np.asarray(freq, float))
+        if sim.nf2ff_mode == "record":
+            return bool(np.all(f <= sim.nf2ff_fmax * (1 + 1e-9)))
+        if self._fdtd._nf2ff_snap:
+            return True
+        rec = np.asarray(sim.nf2ff_freqs, float)
+        return bool(all(np.min(np.abs(rec - x)) <= 1e-6 * max(x, 1.0) for x in f))
+
     def CalcNF2FF(self, sim_path, freq, theta, phi, radius=1, center=(0, 0, 0), outfile=None,
                   read_cached=False, verbose=0):
         """theta/phi in DEGREES, center in metres (fixed.py:296).  Returns an object with the upstream
-        attribute names; arrays are [frequency] lists of (ntheta, nphi)."""
+        attribute names; arrays are [frequency] lists of (ntheta, nphi).
+        Multi-rank runs: Run() has already reduced the faces over the ranks for the excitation's centre frequency (and
+        nf2ff_freqs), so a call for those is LOCAL and may be made on rank 0 alone, as upstream post-processing is.  Any
+        OTHER frequency (time-domain recording) has to be transformed on every rank's slab first: such a call is a
+        collective — every rank must make it, with the same frequencies."""
         return self._fdtd._calc_nf2ff(np.atleast_1d(np.asarray(freq, float)), np.atleast_1d(np.asarray(theta, float)),
                                       np.atleast_1d(np.asarray(phi, float)), float(radius),
                                       np.asarray(center, float))
@@ -352,6 +373,22 @@ class openEMS:
             sc.add_lumped_port(port.number, port.R, port.start, port.stop, port.exc_ny, port.excite, port.priority)
         return grid, sc
 
+    def _port_exponents(self, freq, n, dt):
+        key = (freq.tobytes(), int(n), float(dt))
+        if getattr(self, "_ex_cache", (None, None))[0] != key:
+            self._ex_cache = (key, np.exp(-2j * np.pi * np.outer(freq, np.arange(n) * dt)))
+        return self._ex_cache[1]
+
+    @staticmethod
+    def _wipe_sim_path(sim_path):
+        """cleanup=True, as upstream's engine does before a run (fixed.py:280): a pre-existing sim_path goes.  Never a
+        directory this process runs in (or any of its parents), never a filesystem root."""
+        path = os.path.realpath(sim_path)
+        cwd = os.path.realpath(os.getcwd())
+        if not os.path.isdir(path) or path == os.path.dirname(path) or cwd == path or cwd.startswith(path + os.sep):
+            return
+        shutil.rmtree(path, ignore_errors=True)
+
     def Run(self, sim_path, cleanup=False, setup_only=False, verbose=None, **kw):
         """Time-step on the GPU.  Blocks; ctypes releases the GIL so a GUI thread stays live
         (the reference calls this from one background thread, gui_app.py:2688-2690)."""
@@ -359,6 +396,8 @@ class openEMS:
         self.calls_log.add("Run", verbose=verbose, cleanup=cleanup)
         if self._csx is None or self._f0 is None:
             raise RuntimeError("SetCSX and SetGaussExcite must be called before Run")
+        if cleanup and sim_path and self._rank == 0:
+            self._wipe_sim_path(sim_path)
         lib = self._lib or load_hip_library()
         grid, sc = self._build_scene()
         vox = voxelize(sc, grid)
@@ -387,6 +426,11 @@ class openEMS:
         self._boxes = None
         if self._nf2ff is not None and self.sim.nf2ff_mode == "dft":
             self._boxes = self.sim.nf2ff_boxes(allreduce)
+        elif self._nf2ff is not None and allreduce is not None:
+            # several ranks, faces recorded in the time domain: transform and reduce the frequencies the caller is known to
+            # ask for HERE, where every rank is, so that CalcNF2FF at those is local (rank 0 alone may post-process)
+            f = np.asarray(freqs, float)
+            self._box_cache = {tuple(float(x) for x in f): self.sim.nf2ff_boxes(allreduce, freqs=f)}
         if sim_path and self._rank == 0:
             try:
                 os.makedirs(sim_path, exist_ok=True)
@@ -396,9 +440,12 @@ class openEMS:
                                "steps": self.stats.steps, "seconds": self.stats.seconds,
                                "mcells_per_s": self.stats.mcells_per_s, "energy_db": float(self.stats.energy_db),
                                "operator": self.sim.operator_form, "n_gpus": self._world}, fh)
-                for port, (u, i) in zip(self._ports, self._u_i):
-                    np.savetxt(os.path.join(sim_path, f"port_ut{port.number}"), np.c_[np.arange(u.size) * self.sim.dt, u])
-                    np.savetxt(os.path.join(sim_path, f"port_it{port.number}"), np.c_[(np.arange(i.size) + 0.5) * self.sim.dt, i])
+                # the port series as upstream's probe files (text): only on request — formatting them takes 0.03 s of a
+                # 0.34 s call on the reference's default scene, and CalcPort reads the arrays, not the files
+                if int(verbose or 0) > 0 or os.environ.get("FDTD_WRITE_PORT_FILES"):
+                    for port, (u, i) in zip(self._ports, self._u_i):
+                        np.savetxt(os.path.join(sim_path, f"port_ut{port.number}"), np.c_[np.arange(u.size) * self.sim.dt, u])
+                        np.savetxt(os.path.join(sim_path, f"port_it{port.number}"), np.c_[(np.arange(i.size) + 0.5) * self.sim.dt, i])
             except OSError:
                 pass
 
@@ -420,7 +467,13 @@ class openEMS:
             # with the dumps); cached, since the 3-D variants call once per phi (microstrip_3d.py:224-225)
             key = tuple(float(f) for f in freq)
             if key not in self._box_cache:
-                self._box_cache = {key: self.sim.nf2ff_boxes(self._allreduce, freqs=freq)}
+                hit = [k for k in self._box_cache if all(any(abs(f - g) <= 1e-9 * max(abs(g), 1.0) for g in k) for f in key)]
+                if hit:      # a subset of what is cached (e.g. Run's reduced set): pick the rows
+                    src = hit[0]
+                    rows = [int(np.argmin(np.abs(np.asarray(src) - f))) for f in key]
+                    self._box_cache[key] = [b[rows] for b in self._box_cache[src]]
+                else:        # (with several ranks this is a collective: see CalcNF2FF)
+                    self._box_cache = {key: self.sim.nf2ff_boxes(self._allreduce, freqs=freq)}
             boxes, f_used = self._box_cache[key], freq
         else:
             rec = self.sim.nf2ff_freqs

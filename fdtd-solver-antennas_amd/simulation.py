@@ -24,10 +24,62 @@ from ._capi import Engine, KIND_V, KIND_I
 
 
 def slab_range(nz: int, world: int, rank: int):
-    """Contiguous z-planes [k0, k0+nk) of `rank`; the remainder goes to the first ranks."""
+    """Contiguous z-planes [k0, k0+nk) of `rank`, planes counted alike; the remainder goes to the first ranks."""
     base, rem = divmod(nz, world)
     k0 = rank * base + min(rank, rem)
     return k0, base + (1 if rank < rem else 0)
+
+
+# A z-plane inside a z-directed CPML layer reads and writes four more psi arrays per timestep (+16 of 37 bytes per cell and
+# half-step) than a plane outside: measured on MI355X it costs 1.5x as much (NS: 20 layer planes +10.4 us over 60 planes of
+# 0.95 us; C3: +18.0 us over 80 planes of 1.78 us — profiles/r02/cpml_axis_cost.txt; per-slab times: profiles/r03/slab_balance.txt).
+# With planes counted alike the first and the last rank, which own ALL layer planes, take up to 37 % longer than the interior
+# ranks (C5 on 8 GPUs: 10 of their 15 planes), and every rank waits for its neighbours' halos each half-step.
+Z_LAYER_PLANE_COST = float(os.environ.get("FDTD_SLAB_WZ", "1.5"))
+
+
+def plane_costs(nz: int, cpml_lo: int = 0, cpml_hi: int = 0, w_layer: Optional[float] = None) -> np.ndarray:
+    """Relative cost of every z-plane of the global grid: 1 outside the z-directed CPML layers, `w_layer` inside
+    (planes 0 .. cpml_lo-1 and nz-1-cpml_hi .. nz-1, the planes build_cpml gives psi slots)."""
+    w = np.ones(nz)
+    wl = Z_LAYER_PLANE_COST if w_layer is None else float(w_layer)
+    if cpml_lo:
+        w[:cpml_lo] = wl
+    if cpml_hi:
+        w[nz - 1 - cpml_hi:] = wl
+    return w
+
+
+def slab_partition(costs: Sequence[float], world: int, min_planes: int = 2):
+    """[(k0, nk)] * world: contiguous slabs of at least `min_planes` planes whose largest summed cost is as small as possible
+    (exact: dynamic programme over the cut positions; ties go to the partition with the smaller sum of squared costs).
+    Deterministic, so every rank computes the same cuts."""
+    c = np.asarray(costs, float)
+    nz = c.size
+    if world < 1 or nz < world * min_planes:
+        raise ValueError(f"{nz} planes cannot be cut into {world} slabs of >= {min_planes} planes")
+    pre = np.concatenate([[0.0], np.cumsum(c)])
+    INF = float("inf")
+    # best[r][k] = (largest slab cost, sum of squares) of the first k planes in r slabs
+    best = [[(INF, INF)] * (nz + 1) for _ in range(world + 1)]
+    cut = [[-1] * (nz + 1) for _ in range(world + 1)]
+    best[0][0] = (0.0, 0.0)
+    for r in range(1, world + 1):
+        for k in range(r * min_planes, nz - (world - r) * min_planes + 1):
+            for q in range((r - 1) * min_planes, k - min_planes + 1):
+                m, sq = best[r - 1][q]
+                if m == INF:
+                    continue
+                sc = pre[k] - pre[q]
+                cand = (max(m, sc), sq + sc * sc)
+                if cand[0] < best[r][k][0] - 1e-12 or (abs(cand[0] - best[r][k][0]) <= 1e-12 and cand[1] < best[r][k][1] - 1e-12):
+                    best[r][k], cut[r][k] = cand, q
+    out, k = [], nz
+    for r in range(world, 0, -1):
+        q = cut[r][k]
+        out.append((q, k - q))
+        k = q
+    return out[::-1]
 
 
 @dataclass
@@ -69,6 +121,7 @@ class RunStats:
     mcells_per_s: float = 0.0
     energy_db: float = 0.0
     stopped_by_energy: bool = False
+    schedule_fallback: Optional[str] = None   # set when the run was repeated under the two-launch schedule (see Simulation.run)
 
 
 class Simulation:
@@ -141,10 +194,22 @@ class Simulation:
         return self._op
 
     # ---------------------------------------------------------------------------------------------
-    def build(self, lib, *, rank: int = 0, world: int = 1, device: int = 0, flags: int = 0) -> Engine:
+    def slabs(self, world: int, partition: str = "cost"):
+        """[(k0, nk)] of every rank.  "cost": slabs of equal COST — the z-layer planes weigh Z_LAYER_PLANE_COST, so the two
+        end ranks own fewer planes; "even": equal plane counts (SURVEY §8e's first cut)."""
+        nz = self.grid.shape[2]
+        cells = self.bc.face_cells()
+        if partition == "even" or world == 1 or not (cells[4] or cells[5]):
+            return [slab_range(nz, world, r) for r in range(world)]
+        if partition != "cost":
+            raise ValueError("partition must be 'cost' or 'even'")
+        return slab_partition(plane_costs(nz, cells[4], cells[5]), world)
+
+    def build(self, lib, *, rank: int = 0, world: int = 1, device: int = 0, flags: int = 0, partition: str = "cost") -> Engine:
         g = self.grid
         nx, ny, nz = g.shape
-        k0, nk = slab_range(nz, world, rank)
+        k0, nk = self.slabs(world, partition)[rank]
+        self.partition = partition
         if nk < 2:
             raise ValueError(f"slab of rank {rank} has {nk} planes; need >= 2")
         e = Engine(lib, nx, ny, nz, self.dt, k0=k0, nk=nk, rank=rank, world=world, device=device,
@@ -193,6 +258,7 @@ class Simulation:
                 self._nf_ids = self.nf2ff_box.register(e)
         self.engine, self.lib = e, lib
         self.rank, self.world, self.device = rank, world, device
+        self._build_flags = int(flags)
         return e
 
     # ---------------------------------------------------------------------------------------------
@@ -207,12 +273,28 @@ class Simulation:
         emax, stats = 0.0, RunStats()
         t0 = time.perf_counter()
         done = e.step
+        fresh = done == 0          # stepping from the state build() left: a repeat from scratch reproduces it
         while done < total:
             n = min(check_every, total - done)
             if self.external_transport is not None:
                 self.external_transport.run_steps(e, n)
             else:
-                e.run(n)
+                try:
+                    e.run(n)
+                except _capi.FdtdError as exc:
+                    # The one-launch-per-timestep schedule depends on workgroups being dispatched in order; a block that
+                    # waits too long for an earlier block's flag sets an error word and the run comes back invalid
+                    # (never a hang).  Heal it here: a new context under the two-launch schedule (no flags, no
+                    # dependence on dispatch order), same process, from the initial state — once.
+                    if not (fresh and self.world == 1 and "wavefront schedule" in str(exc) and stats.schedule_fallback is None):
+                        raise
+                    log(f"[fdtd-hip] {exc} — repeating the run under the two-launch schedule")
+                    e.close()
+                    e = self.build(self.lib, rank=self.rank, world=self.world, device=self.device, partition=self.partition,
+                                   flags=(self._build_flags & ~_capi.FLAG_KERNEL_MASK) | _capi.FLAG_KERNEL_DIRECT)
+                    stats.schedule_fallback = str(exc)
+                    done, emax = 0, 0.0
+                    continue
             done += n
             sv, si = e.energy()
             s = np.array([sv, si])

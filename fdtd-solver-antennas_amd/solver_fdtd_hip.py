@@ -12,6 +12,10 @@ three-call protocol, keyword arguments and result shape:
     run_prepared_hip(prepared, frequency_hz=, verbose=)  <- run_prepared_openems_*  fixed.py:257, microstrip.py:369,
                                                             microstrip_3d.py:199, multi_3d.py:596, openems.py:271
 
+The far field is evaluated at ``frequency_hz`` for every variant, as the reference effectively does; the S11
+resonance rule its microstrip variant spells out but never reaches (microstrip.py:393,407-433) is opt-in:
+``prepared.pattern_at_resonance = True``.
+
 ``dll_dir`` is reinterpreted as the directory holding libfdtd_hip.so (None/"" = the in-tree build).
 Functions never raise: failures come back as ``ok=False`` + message, like upstream
 (fixed.py:253-254,341-342).  The scenes are written against ``openems_api`` (the mirror of the
@@ -84,8 +88,10 @@ class FDTDPrepared:
     port: Optional[object] = None           # first port (upstream forgot to keep it: microstrip.py:393)
     ports: List[object] = field(default_factory=list)
     variant: str = "fixed"
-    # far field at the S11 resonance instead of frequency_hz: None = as the reference's variant does (only the
-    # microstrip variant searches, microstrip.py:407-433; fixed.py:289 and the 3-D variants use frequency_hz)
+    # True: far field at the S11 resonance instead of frequency_hz — what the reference's microstrip variant WRITES
+    # (microstrip.py:407-433) but never DOES: its OpenEMSPrepared has no `port` field, so getattr(prepared, 'port', None) at
+    # :393 is always None and f_res stays frequency_hz.  None / False = the reference's effective behaviour (every variant
+    # evaluates at frequency_hz); the resonance rule is opt-in.
     pattern_at_resonance: Optional[bool] = None
 
 
@@ -568,10 +574,10 @@ def run_prepared_hip(prepared: FDTDPrepared, *, frequency_hz: float, verbose: in
         # port parameters first (microstrip.py:407-426): the resonance they give is where the microstrip variant
         # takes its far field (:433)
         s11_out = s11_from_port(prepared.port, sim_path, frequency_hz) if prepared.port is not None else None
-        at_res = prepared.pattern_at_resonance
-        if at_res is None:
-            at_res = prepared.variant == "microstrip"
+        at_res = bool(prepared.pattern_at_resonance)     # None: as the reference effectively does — at frequency_hz
         f_eval = float(s11_out[3]) if (at_res and s11_out is not None) else float(frequency_hz)
+        if f_eval != float(frequency_hz) and not nf.can_evaluate(f_eval):
+            f_eval = float(frequency_hz)                 # running-DFT faces at caller-named frequencies: the resonance was not recorded
         res = nf.CalcNF2FF(sim_path, f_eval, th_deg, ph_deg, center=prepared.nf_center)
         E = np.asarray(res.E_norm[0])
         Dmax = float(np.asarray(res.Dmax)[0])

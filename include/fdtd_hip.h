@@ -68,7 +68,13 @@ enum { FDTD_HALO_H_UP = 0, FDTD_HALO_E_DOWN = 1 };   /* Ix,Iy top plane -> rank+
 
 /* Kernel selection (fdtd_desc.flags). */
 enum {
-  FDTD_FLAG_KERNEL_AUTO   = 0,   /* the schedule measured faster: one launch per step (below) on single slabs without Mur faces, else two */
+  FDTD_FLAG_KERNEL_AUTO   = 0,   /* the schedule measured faster (fdtd_schedule_info tells which one a context took).  One launch per
+                                    timestep (WAVEFRONT below) where it is possible — no Mur faces, at least 2 planes, rows of at most
+                                    30 720 cells — AND: on a single slab, when the fields exceed the 256 MiB Infinity Cache, or the slab
+                                    has CPML layers, or a sweep has >= 3000 blocks of 1024 cells; on a slab of a decomposed grid (p2p
+                                    mailbox transport only), when the fields exceed the Infinity Cache or a sweep has >= 1800 blocks.
+                                    Else two launches (three with Mur faces).  Slabs of different size may therefore step under
+                                    different schedules in one run; the results do not depend on it. */
   FDTD_FLAG_KERNEL_DIRECT = 1,   /* the same, named explicitly */
   /* 2..4 were one-pass (fused E+H) variants — per-thread recompute, overlapped LDS tiles, z-marching tiles (round 1), and a
      z-marching kernel on an LDS-DMA ring (round 2, git history).  All were bit-exact and all measured slower than the two
@@ -79,13 +85,17 @@ enum {
                                     run first, then all H blocks.  DIRECT never takes it.  Results are identical to the
                                     two-pass kernels bit for bit.  fdtd_profile.fused = 1: ms_update_e is the whole timestep's launch. */
   FDTD_FLAG_KERNEL_MASK   = 0xF,
-  FDTD_FLAG_NO_GRAPH      = 0x10, /* reserved */
   FDTD_FLAG_OVERLAP_ON    = 0x20, /* multi-slab: split sweeps into interior + halo-dependent plane (the default) */
   FDTD_FLAG_OVERLAP_OFF   = 0x40, /* multi-slab: one launch per sweep, after the halo has arrived */
   FDTD_FLAG_LOOPBACK      = 0x80  /* transport self-test on ONE GPU: an interior slab (0 < rank < world-1) exchanges
                                      both halos with ITSELF — fdtd_comm_init makes a communicator of one rank and every
                                      ncclSend/ncclRecv of the step loop is a self send/recv.  Same result as driving
-                                     fdtd_half_step + fdtd_halo_get/put back into the same context. */
+                                     fdtd_half_step + fdtd_halo_get/put back into the same context.
+                                     With the p2p mailbox transport (fdtd_p2p_attach(ctx, own blob, own blob)) ANY slab of a
+                                     decomposition can be timed alone on one GPU: it pulls the halos a slab in its place pulls
+                                     (none below rank 0, none above the last rank) and pushes BOTH of its halo planes into its
+                                     own mailbox (an end slab thereby pushes one plane more than it would in a real run: its
+                                     time is an upper bound).  Fields are meaningless; tools/slab_balance.py. */
 };
 
 typedef struct fdtd_ctx fdtd_ctx;
@@ -208,6 +218,14 @@ int fdtd_run(fdtd_ctx* ctx, int nsteps);
 /* Same (1..4096 steps), with start / stop events on every main-kernel launch: their begin / end timestamps. */
 int fdtd_run_profiled(fdtd_ctx* ctx, int nsteps, fdtd_profile* out);
 int fdtd_get_step(fdtd_ctx* ctx, int64_t* step);
+/* The step schedule this context runs under its current flags, boundaries and transport:
+ *   info[0] main-kernel launches per timestep (1: k_step, 2: update_E + update_H, 3: with Mur faces; 0: driven by
+ *           fdtd_half_step / not steppable yet)
+ *   info[1] one launch per timestep only: planes the E sweep runs ahead of the H sweep (== nk: all E blocks, then all H blocks)
+ *   info[2] rows per strip, info[3] blocks (of 1024 cells) per sweep
+ *   info[4] halo transport: 0 none (single slab), 1 p2p mailbox, 2 RCCL, 3 linked contexts, 4 external (fdtd_half_step)
+ *   info[5] 1 if the XCD shares are cost-weighted (CPML layers present), info[6..7] reserved (0) */
+int fdtd_schedule_info(fdtd_ctx* ctx, int32_t info[8]);
 /* sums[0] = sum V^2, sums[1] = sum I^2 over the owned planes. */
 int fdtd_energy(fdtd_ctx* ctx, double sums[2]);
 
@@ -231,9 +249,22 @@ int fdtd_comm_nranks(fdtd_ctx* ctx, int* nranks);
 int fdtd_p2p_export(fdtd_ctx* ctx, void* out128);
 int fdtd_p2p_attach(fdtd_ctx* ctx, const void* lower128, const void* upper128);
 /* Hand-shake with the attached neighbours (token written into their mailboxes, theirs awaited for <= 10 s): call on
- * all ranks at about the same time, before the first step.  Error = fall back (fdtd_p2p_detach, then e.g. RCCL). */
+ * all ranks at about the same time, before the first step.  Error = fall back (fdtd_p2p_detach, then e.g. RCCL).
+ * The test ends by zeroing THIS rank's mailbox.  Callers must therefore synchronise all ranks (a barrier) between the
+ * self-test and the first fdtd_run: a neighbour that starts stepping earlier pushes its initial halo (tag 1) into a
+ * mailbox this rank may still be verifying or zeroing.  (distributed.SlabComm.attach does: its agreement all-reduce.) */
 int fdtd_p2p_selftest(fdtd_ctx* ctx, unsigned token);
 int fdtd_p2p_detach(fdtd_ctx* ctx);
+/* The link between this context's GPU and an attached neighbour's (which: 0 = lower rank, 1 = upper rank), so that a
+ * multi-GPU record can tell an xGMI neighbour from a PCIe one:
+ *   info[0] neighbour's device ordinal in THIS process (-1: not attached; -2: attached, but that GPU is not visible here)
+ *   info[1] 1 same process (plain pointer), 2 another process (HIP IPC mapping)
+ *   info[2] link type   (hipExtGetLinkTypeAndHopCount: HSA_AMD_LINK_INFO_TYPE_*: 0 HyperTransport, 1 QPI, 2 PCIe, 3 InfiniBand, 4 xGMI)
+ *   info[3] hop count   (same call; 0 for the same device)
+ *   info[4] hipDevP2PAttrPerformanceRank, info[5] hipDevP2PAttrAccessSupported, info[6] hipDevP2PAttrNativeAtomicSupported
+ *   info[7] 1 if the neighbour is this very device (several ranks on one GPU, or a loopback slab)
+ * Entries the runtime cannot tell are -1. */
+int fdtd_p2p_link_info(fdtd_ctx* ctx, int which, int32_t info[8]);
 /* (a') Several slabs inside ONE process (one host thread driving several GPUs, or several slabs on one GPU):
  *      link adjacent contexts, then step them together; halos move by peer copies on the communication
  *      streams with the same overlapped schedule as the RCCL path. ctxs[r] must be rank r of a world of n. */

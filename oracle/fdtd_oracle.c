@@ -795,6 +795,18 @@ int fdtd_p2p_export(fdtd_ctx* c, void* out128) { (void)out128; return fail(c, FD
 int fdtd_p2p_attach(fdtd_ctx* c, const void* lo, const void* hi) { (void)lo; (void)hi; return fail(c, FDTD_E_UNSUPPORTED, "oracle has no device transport"); }
 int fdtd_p2p_selftest(fdtd_ctx* c, unsigned token) { (void)token; return fail(c, FDTD_E_UNSUPPORTED, "oracle has no device transport"); }
 int fdtd_p2p_detach(fdtd_ctx* c) { return c ? FDTD_OK : FDTD_E_ARG; }
+int fdtd_p2p_link_info(fdtd_ctx* c, int which, int32_t info[8]) {
+  if (!c || !info || (which != 0 && which != 1)) return FDTD_E_ARG;
+  for (int q = 0; q < 8; ++q) info[q] = -1;   /* never attached */
+  return FDTD_OK;
+}
+/* the oracle steps one half-step at a time (fdtd_run = fdtd_half_step E, H in a loop): no launches, no tiling */
+int fdtd_schedule_info(fdtd_ctx* c, int32_t info[8]) {
+  if (!c || !info) return FDTD_E_ARG;
+  for (int q = 0; q < 8; ++q) info[q] = 0;
+  info[4] = c->d.world > 1 ? 4 : 0;
+  return FDTD_OK;
+}
 int fdtd_comm_unique_id(void* out128) { (void)out128; return fail(NULL, FDTD_E_UNSUPPORTED, "oracle has no RCCL transport"); }
 int fdtd_comm_init(fdtd_ctx* c, const void* uid) { (void)uid; return fail(c, FDTD_E_UNSUPPORTED, "oracle has no RCCL transport"); }
 int fdtd_comm_nranks(fdtd_ctx* c, int* nranks) { if (!c || !nranks) return FDTD_E_ARG; *nranks = 0; return FDTD_OK; }

@@ -60,5 +60,5 @@ def test_flag_constants_of_the_binding_match_the_header():
     capi = pkg("_capi")
     text = open(os.path.join(ROOT, "include", "fdtd_hip.h")).read()
     enum = dict((m.group(1), int(m.group(2), 0)) for m in re.finditer(r"\b(FDTD_FLAG_\w+)\s*=\s*(0x[0-9A-Fa-f]+|\d+)", text))
-    for name in ("KERNEL_AUTO", "KERNEL_DIRECT", "KERNEL_WAVEFRONT", "NO_GRAPH", "OVERLAP_ON", "OVERLAP_OFF", "LOOPBACK"):
+    for name in ("KERNEL_AUTO", "KERNEL_DIRECT", "KERNEL_WAVEFRONT", "KERNEL_MASK", "OVERLAP_ON", "OVERLAP_OFF", "LOOPBACK"):
         assert getattr(capi, "FLAG_" + name) == enum["FDTD_FLAG_" + name], name
