@@ -531,10 +531,11 @@ def prepare_hip_patch(params, *, dll_dir: Optional[str] = None, work_dir: str = 
 # ---------------------------------------------------------------------------------------------------
 def pattern_to_dBi(E_norm: np.ndarray, Dmax: Optional[float], variant: str = "fixed") -> np.ndarray:
     """The only arithmetic the reference owns (fixed.py:309-315; microstrip.py:454-455;
-    microstrip_3d.py:240-248; multi_3d.py:635-642): 20 log10(E/Emax [+1e-16]) + 10 log10(Dmax)."""
+    microstrip_3d.py:240-248; multi_3d.py:635-642): 20 log10(E/Emax [+1e-16]) + 10 log10(Dmax).
+    (The legacy variant converts differently: legacy_pattern.)"""
     E = np.asarray(E_norm, dtype=float)
     e_max = float(np.max(E)) if E.size else 1.0
-    if variant in ("microstrip_3d", "multi_3d", "legacy"):
+    if variant in ("microstrip_3d", "multi_3d"):
         if e_max <= 0:
             e_max = 1.0
         out = 20.0 * np.log10(E / e_max + 1e-16)
@@ -542,6 +543,62 @@ def pattern_to_dBi(E_norm: np.ndarray, Dmax: Optional[float], variant: str = "fi
     if variant == "fixed" and e_max <= 0:
         return np.full_like(E, -50.0)
     return 20.0 * np.log10(E / e_max) + 10 * np.log10(Dmax)
+
+
+def legacy_pattern(res, n_theta: int, n_phi: int):
+    """(intensity (n_theta, n_phi), is_dBi) of the LEGACY variant, which sniffs the attributes of the NF2FF result
+    (solver_fdtd_openems.py:307-408): directivity 4 pi P_rad / Prad in dBi when both are there; if that comes out below
+    -10 dBi everywhere ("obviously wrong") E_norm + Dmax as the tutorials do; without P_rad / Prad the normalised
+    |E_theta|^2 + |E_phi|^2 (or any magnitude array), linear, is_dBi False.  Then the grid is forced to (n_theta, n_phi)."""
+    def first(*names):
+        for n in names:
+            if hasattr(res, n):
+                return getattr(res, n)
+        return None
+
+    e_th, e_ph = first("E_theta", "Eth", "E_th", "Etheta"), first("E_phi", "Eph", "E_ph", "Ephi")
+    p_rad, prad = first("P_rad", "P", "U"), first("Prad", "Ptot", "P_rad_tot")
+    arr, dbi = None, False
+    if p_rad is not None and prad is not None:
+        try:
+            g = np.asarray(p_rad)
+            g = np.asarray(g[0] if g.ndim == 3 else g, dtype=float)
+            arr = 10.0 * np.log10(np.maximum(1e-16, g / max(1e-16, float(np.asarray(prad).flat[0])) * (4.0 * np.pi)))
+            dbi = True
+        except Exception:
+            arr, dbi = None, False
+    if dbi and (np.nanmax(arr) < -10.0 or np.isnan(np.nanmax(arr))):
+        e_norm, dmax = first("E_norm"), first("Dmax")
+        if e_norm is not None and dmax is not None:
+            try:
+                g = np.asarray(e_norm)
+                g = np.array(g[0] if g.ndim == 3 else g, dtype=float)
+                g /= max(1e-16, float(g.max()))
+                arr = 20.0 * np.log10(np.maximum(1e-16, g)) + 10.0 * np.log10(max(1e-16, float(np.asarray(dmax).flat[0])))
+            except Exception:
+                pass
+    if arr is None:
+        if e_th is None or e_ph is None:
+            u = first("U", "Gain", "E_norm")
+            if u is None:
+                raise ValueError("NF2FF result has no usable field data")
+            lin = np.abs(u).astype(float)
+        else:
+            lin = (np.abs(e_th) ** 2 + np.abs(e_ph) ** 2).astype(float)
+        arr, dbi = lin / max(1e-16, float(np.max(lin))), False
+    n = n_theta * n_phi
+    if arr.size == n:
+        arr = arr.reshape(n_theta, n_phi)
+    elif arr.size > n:
+        arr = arr.flat[:n].reshape(n_theta, n_phi)
+    else:
+        pad = np.zeros((n_theta, n_phi))
+        pad.flat[:arr.size] = arr.flat
+        arr = pad
+    arr = np.asarray(arr, dtype=float)
+    if not dbi:
+        arr = arr / max(1e-16, float(arr.max()))
+    return arr, dbi
 
 
 def s11_from_port(port, sim_path, f_center: float, npts: int = 201):
@@ -566,8 +623,8 @@ def run_prepared_hip(prepared: FDTDPrepared, *, frequency_hz: float, verbose: in
         sim_path = prepared.sim_path or "fdtd_hip_out"
         if verbose:
             print(f"[fdtd-hip] starting FDTD ({prepared.variant}) in: {sim_path}", flush=True)
-        fdtd.Run(sim_path, verbose=verbose, cleanup=True)
         legacy = prepared.variant == "legacy"
+        fdtd.Run(sim_path, verbose=verbose, cleanup=not legacy)      # (the legacy variant keeps a pre-existing sim_path: openems.py:289)
         th = np.asarray(prepared.theta, dtype=float)
         ph = np.asarray(prepared.phi, dtype=float)
         th_deg, ph_deg = (np.rad2deg(th), np.rad2deg(ph)) if legacy else (th, ph)
@@ -579,11 +636,15 @@ def run_prepared_hip(prepared: FDTDPrepared, *, frequency_hz: float, verbose: in
         if f_eval != float(frequency_hz) and not nf.can_evaluate(f_eval):
             f_eval = float(frequency_hz)                 # running-DFT faces at caller-named frequencies: the resonance was not recorded
         res = nf.CalcNF2FF(sim_path, f_eval, th_deg, ph_deg, center=prepared.nf_center)
-        E = np.asarray(res.E_norm[0])
         Dmax = float(np.asarray(res.Dmax)[0])
-        intensity = pattern_to_dBi(E, Dmax, prepared.variant)
-        out = FDTDResult(True, f"fdtd-hip FDTD completed ({prepared.variant})", theta=np.deg2rad(th_deg),
-                         phi=np.deg2rad(ph_deg), intensity=intensity, sim_path=sim_path, is_dBi=True, Dmax=Dmax)
+        if legacy:      # attribute-sniffing conversion; theta / phi go out as they came in (radians), openems.py:408
+            intensity, is_dbi = legacy_pattern(res, th.size, ph.size)
+            th_out, ph_out = th, ph
+        else:
+            intensity, is_dbi = pattern_to_dBi(np.asarray(res.E_norm[0]), Dmax, prepared.variant), True
+            th_out, ph_out = np.deg2rad(th_deg), np.deg2rad(ph_deg)
+        out = FDTDResult(True, f"fdtd-hip FDTD completed ({prepared.variant})", theta=th_out,
+                         phi=ph_out, intensity=intensity, sim_path=sim_path, is_dBi=is_dbi, Dmax=Dmax)
         out.f_pattern = float(np.atleast_1d(res.freq)[0])     # == f_eval unless a dft-mode comb snapped it
         if s11_out is not None:
             out.freq, out.s11, out.s11_dB, out.f_res = s11_out

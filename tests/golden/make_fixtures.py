@@ -42,6 +42,19 @@ class Recorder:
         self.calls.append({"op": op, **{k: _f(v) for k, v in kw.items()}})
 
 
+def legacy_synthetic(th, ph):
+    """Synthetic far field for the legacy variant's conversion: complex E_theta / E_phi on the theta x phi grid (radians,
+    broadcast shapes), P_rad = |E|^2 / (2 eta0), Prad = its integral over the sphere (rectangle rule), Dmax = 4 pi max(P_rad) / Prad.
+    tests/test_plugin_surface_cpu.py builds the same arrays to check this package's conversion against the fixture."""
+    e_th = np.cos(th / 2.0) ** 2 * (1.0 + 0.25 * np.cos(ph)) * np.exp(0.3j) + 0j
+    e_ph = 0.3 * np.sin(th) * np.sin(ph) * np.exp(-0.7j) + 0j
+    p_rad = (np.abs(e_th) ** 2 + np.abs(e_ph) ** 2) / (2.0 * 376.730313668)
+    dth = float(th[1, 0] - th[0, 0]) if th.shape[0] > 1 else 1.0
+    dph = float(ph[0, 1] - ph[0, 0]) if ph.shape[1] > 1 else 1.0
+    prad = float(np.sum(p_rad * np.sin(th)) * dth * dph)
+    return e_th, e_ph, p_rad, prad, float(4.0 * np.pi * p_rad.max() / prad)
+
+
 def install_fake(rec: Recorder):
     class Box:
         def __init__(self, entry):
@@ -83,14 +96,33 @@ def install_fake(rec: Recorder):
             return Prop("Metal", name)
 
     class NF2FF:
+        # what the synthetic result object carries: "enorm" (E_norm + Dmax: all the newer variants read), or, for the
+        # legacy variant's attribute-sniffing conversion (solver_fdtd_openems.py:307-408), "full" (every attribute the
+        # nf2ff tool gives), "weak" (the same with P_rad a factor 1e-4 too small, so that the directivity from
+        # P_rad / Prad looks "obviously wrong" and the E_norm + Dmax branch takes over), "fields" (E_theta, E_phi only)
+        mode = "enorm"
+
         def CalcNF2FF(self, sim_path, freq, theta, phi, center=None, **kw):
             theta = np.atleast_1d(np.asarray(theta, float)); phi = np.atleast_1d(np.asarray(phi, float))
-            rec.add("CalcNF2FF", freq=freq, ntheta=int(theta.size), nphi=int(phi.size), center=center)
+            rec.add("CalcNF2FF", freq=freq, ntheta=int(theta.size), nphi=int(phi.size), center=center,
+                    theta_first_last=[float(theta[0]), float(theta[-1])], phi_first_last=[float(phi[0]), float(phi[-1])])
             th = np.deg2rad(theta)[:, None]; ph = np.deg2rad(phi)[None, :]
             res = types.SimpleNamespace()
-            res.E_norm = [np.cos(th / 2.0) ** 2 * (1.0 + 0.25 * np.cos(ph)) + 1e-3]
-            res.Dmax = [4.0]
+            if NF2FF.mode == "enorm":
+                res.E_norm = [np.cos(th / 2.0) ** 2 * (1.0 + 0.25 * np.cos(ph)) + 1e-3]
+                res.Dmax = [4.0]
+                return res
+            e_th, e_ph, p_rad, prad, dmax = legacy_synthetic(th, ph)
+            if NF2FF.mode in ("full", "weak"):
+                res.E_theta, res.E_phi = [e_th], [e_ph]
+                res.E_norm = [np.sqrt(np.abs(e_th) ** 2 + np.abs(e_ph) ** 2)]
+                res.P_rad = [p_rad * (1e-4 if NF2FF.mode == "weak" else 1.0)]
+                res.Prad, res.Dmax = [prad], [dmax]
+            else:
+                res.E_theta, res.E_phi = e_th, e_ph
             return res
+
+    install_fake.NF2FF = NF2FF
 
     class FDTD:
         def __init__(self, NrTS=None, EndCriteria=None, **kw):
@@ -215,10 +247,17 @@ def main():
     # ---- result conversion ------------------------------------------------------------------------
     conv = {}
 
-    def run(fn, prep, f):
+    def run(fn, prep, f, sub=None):
         rec.calls = []
         r = fn(prep, frequency_hz=f, verbose=0)
         assert r.ok, r.message
+        if sub is not None:      # a 91 x 181 grid: every sub[0]-th row and sub[1]-th column, the shape and two checksums
+            a = np.asarray(r.intensity, float)
+            return {"theta": _f(r.theta), "phi": _f(r.phi), "shape": list(a.shape), "sub": list(sub),
+                    "intensity_sub": _f(a[::sub[0], ::sub[1]]), "sum": float(a.sum()), "sum_sq": float((a * a).sum()),
+                    "is_dBi": bool(r.is_dBi), "message": r.message,
+                    "calc_calls": [c for c in rec.calls if c["op"] == "CalcNF2FF"][:3],
+                    "n_calc_calls": sum(1 for c in rec.calls if c["op"] == "CalcNF2FF")}
         return {"theta": _f(r.theta), "phi": _f(r.phi), "intensity": _f(r.intensity), "is_dBi": bool(r.is_dBi),
                 "message": r.message, "calc_calls": [c for c in rec.calls if c["op"] == "CalcNF2FF"][:3],
                 "n_calc_calls": sum(1 for c in rec.calls if c["op"] == "CalcNF2FF")}
@@ -227,6 +266,12 @@ def main():
     conv["microstrip"] = run(ms.run_prepared_openems_microstrip, prep_ms, 2.45e9)
     conv["microstrip3d"] = run(m3.run_prepared_openems_microstrip_3d, prep_3d, 5.8e9)
     conv["multi"] = run(mm.run_prepared_openems_microstrip_multi_3d, prep_mm, 2.45e9)
+    # legacy variant: radian theta/phi in Prepared (openems.py:262-263), degrees handed to CalcNF2FF (:299-300), result in
+    # radians; three branches of the conversion (:330-408)
+    for mode, key in (("full", "legacy"), ("weak", "legacy_enorm_fallback"), ("fields", "legacy_fields_only")):
+        install_fake.NF2FF.mode = mode
+        conv[key] = run(lg.run_prepared_openems, prep_lg, 2.45e9, sub=(5, 9))
+    install_fake.NF2FF.mode = "enorm"
     json.dump(conv, open(os.path.join(OUT, "result_conversion.json"), "w"))
 
     # ---- input model ------------------------------------------------------------------------------

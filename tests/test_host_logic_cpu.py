@@ -43,6 +43,52 @@ def test_slab_range_partitions():
             assert max(nk for _, nk in parts) - min(nk for _, nk in parts) <= 1
 
 
+def test_cost_weighted_slab_partition():
+    """simulation.slab_partition: contiguous, complete, >= 2 planes per slab, never worse than the even split in its own
+    cost model, and within 8 % of perfect balance on the BASELINE decompositions (C5 over 8, C4 over 4)."""
+    sim = pkg("simulation")
+    for nz, world, cl in ((60, 8, 10), (60, 4, 10), (60, 2, 10), (128, 4, 10), (120, 8, 10), (40, 2, 10), (16, 5, 3), (36, 3, 8)):
+        cost = sim.plane_costs(nz, cl, cl)
+        assert cost.size == nz and (cost > 1).sum() == 2 * cl + 1           # the top layer runs through the last (inert) line
+        parts = sim.slab_partition(cost, world)
+        assert parts[0][0] == 0 and sum(nk for _, nk in parts) == nz and all(nk >= 2 for _, nk in parts)
+        for (a, n), (b, _) in zip(parts[:-1], parts[1:]):
+            assert a + n == b
+        mine = [cost[a:a + n].sum() for a, n in parts]
+        even = [cost[a:a + n].sum() for a, n in (sim.slab_range(nz, world, r) for r in range(world))]
+        assert max(mine) <= max(even) + 1e-12
+        assert parts == sim.slab_partition(cost, world)                          # deterministic: every rank computes it alone
+        if (nz, world) in ((120, 8), (128, 4)):
+            assert max(mine) / np.mean(mine) <= 1.08 and max(even) / np.mean(even) > 1.08
+    with pytest.raises(ValueError):
+        sim.slab_partition(np.ones(7), 4)
+    # Simulation.slabs: cost-weighted by default when there are z layers, even otherwise / on request
+    s = patch_sim(40, 40, 60, cpml_cells=10, nr_ts=10, nf2ff=False)
+    assert s.slabs(1) == [(0, 60)] and s.slabs(4, "even") == [sim.slab_range(60, 4, r) for r in range(4)]
+    assert [nk for _, nk in s.slabs(4)] == [12, 18, 18, 12]
+    assert patch_sim(40, 40, 60, boundary="PEC", nr_ts=10, nf2ff=False).slabs(4) == s.slabs(4, "even")
+
+
+def test_run_cleanup_wipes_a_stale_sim_path(oracle_lib, tmp_path, monkeypatch):
+    """openems_api.Run(sim_path, cleanup=True) removes a pre-existing sim_path first, as the reference's engine does
+    (fixed.py:280) — but never the directory the process runs in; the port text files are only written on request."""
+    import os
+    import tutorial_scene
+    stale = tmp_path / "run" / "old_dump.h5"
+    stale.parent.mkdir()
+    stale.write_text("x")
+    r = tutorial_scene.build_and_run(oracle_lib, str(tmp_path / "run"), nr_ts=40)
+    assert r["steps"] == 40 and not stale.exists() and os.path.isfile(tmp_path / "run" / "fdtd_hip_run.json")
+    assert not os.path.exists(tmp_path / "run" / "port_ut1")
+    keep = tmp_path / "cwd" / "precious.txt"
+    keep.parent.mkdir()
+    keep.write_text("x")
+    monkeypatch.chdir(keep.parent)
+    monkeypatch.setenv("FDTD_WRITE_PORT_FILES", "1")
+    tutorial_scene.build_and_run(oracle_lib, str(keep.parent), nr_ts=40)
+    assert keep.exists() and os.path.isfile(keep.parent / "port_ut1") and os.path.isfile(keep.parent / "port_it1")
+
+
 def test_cpml_slab_tables_are_end_anchored():
     s = patch_sim(40, 40, 60, cpml_cells=10, nr_ts=10, nf2ff=False)
     n_full = None

@@ -39,26 +39,33 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one(oracle_lib, tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_equal_one(oracle_lib, tmp_path, world):
+    """world 3: the cost-weighted partition (simulation.slab_partition) gives the two end ranks, which own all z-CPML
+    planes, fewer planes than the middle one — the uneven slabs must still reproduce the single slab bit for bit."""
     import torch.multiprocessing as mp
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     s = patch_sim(*SHAPE, cpml_cells=8, nr_ts=STEPS)
     e = s.build(oracle_lib)
     e.run(STEPS)
-    r = [np.load(tmp_path / f"rank{q}.npz") for q in range(2)]
-    assert int(r[0]["k0"]) == 0 and int(r[0]["nk"]) + int(r[1]["nk"]) == SHAPE[2]
+    r = [np.load(tmp_path / f"rank{q}.npz") for q in range(world)]
+    nks = [int(q["nk"]) for q in r]
+    assert int(r[0]["k0"]) == 0 and sum(nks) == SHAPE[2]
+    assert [(int(q["k0"]), int(q["nk"])) for q in r] == s.slabs(world)
+    if world == 3:
+        assert nks[1] > nks[0] and nks[1] > nks[2]
     assert int(r[0]["steps"]) == STEPS
-    both = np.concatenate([r[0]["fields"], r[1]["fields"]], axis=2)
+    both = np.concatenate([q["fields"] for q in r], axis=2)
     ref = e.fields()
     assert np.abs(ref).max() > 0
     assert np.array_equal(both.view(np.uint32), ref.view(np.uint32))
     u, i = s.port_series()[0]
-    assert np.allclose(r[0]["u"], u, rtol=1e-12, atol=0) and np.allclose(r[1]["i"], i, rtol=1e-12, atol=1e-300)
+    assert np.allclose(r[0]["u"], u, rtol=1e-12, atol=0) and np.allclose(r[-1]["i"], i, rtol=1e-12, atol=1e-300)
     for n, b in enumerate(s.nf2ff_boxes()):
-        assert np.allclose(r[0][f"box{n}"], b, rtol=1e-12, atol=1e-30)
-        assert np.allclose(r[1][f"box{n}"], b, rtol=1e-12, atol=1e-30)
+        for q in r:
+            assert np.allclose(q[f"box{n}"], b, rtol=1e-12, atol=1e-30)
     sv, si = e.energy()
     assert np.allclose(r[0]["en"], [sv, si], rtol=1e-12)

@@ -634,7 +634,8 @@ def test_recorder_equals_running_dft_and_oracle(hip_lib, oracle_lib):
 
 
 def test_far_field_taken_at_the_s11_resonance(hip_lib, oracle_lib, tmp_path):
-    """Row a13 completed: the microstrip variant picks f_res from S11 and evaluates CalcNF2FF THERE
+    """Row a13 completed (opt-in: prepared.pattern_at_resonance = True — the reference spells the rule out but never
+    reaches it): the microstrip variant picks f_res from S11 and evaluates CalcNF2FF THERE
     (solver_fdtd_openems_microstrip.py:407-433) — possible because the NF2FF faces are recorded in the time domain.
     HIP vs oracle: same f_res, pattern frequency == f_res (the dip is below -10 dB), cuts within 1e-3; and the
     dft-mode fallback (comb) snaps to its nearest recorded frequency and says so in f_pattern."""
@@ -648,6 +649,7 @@ def test_far_field_taken_at_the_s11_resonance(hip_lib, oracle_lib, tmp_path):
         assert prep.ok, prep.message
         assert prep.variant == "microstrip"
         prep.FDTD.NrTS = 9000
+        prep.pattern_at_resonance = True
         r = s.run_prepared_hip(prep, frequency_hz=p.frequency_hz, verbose=0)
         assert r.ok, r.message
         assert prep.FDTD.sim.nf2ff_mode == "record"
@@ -663,6 +665,7 @@ def test_far_field_taken_at_the_s11_resonance(hip_lib, oracle_lib, tmp_path):
     prep = s.prepare_hip_microstrip_patch(p, feed_direction=s.FeedDirection.NEG_X, boundary="MUR",
                                           work_dir=str(tmp_path / "comb"), nf2ff_mode="dft")
     prep.FDTD.NrTS = 9000
+    prep.pattern_at_resonance = True
     r = s.run_prepared_hip(prep, frequency_hz=p.frequency_hz, verbose=0)
     assert r.ok, r.message
     comb = pkg("openems_api").nf2ff_comb(p.frequency_hz)

@@ -124,6 +124,79 @@ def test_result_conversion_matches_reference(variant, key):
     assert gold["is_dBi"] is True
 
 
+@pytest.mark.parametrize("key,mode", [("legacy", "full"), ("legacy_enorm_fallback", "weak"), ("legacy_fields_only", "fields")])
+def test_legacy_result_conversion_matches_reference(key, mode):
+    """The legacy variant (solver_fdtd_openems.py:271-411): radian theta / phi in Prepared, DEGREES handed to CalcNF2FF,
+    radians out; its three conversion branches — directivity from P_rad / Prad, E_norm + Dmax when that looks wrong,
+    normalised |E|^2 (linear, is_dBi False) when only the field components exist — against what the reference made of
+    the same synthetic far field (tests/golden/make_fixtures.py: legacy_synthetic)."""
+    import types
+    gold = _load("result_conversion.json")[key]
+    s = pkg("solver_fdtd_hip")
+    prep = s.prepare_hip_patch(_params())
+    assert prep.ok and prep.variant == "legacy"
+    _same(np.asarray(prep.theta).tolist(), gold["theta"], "theta")        # radians already in Prepared ...
+    _same(np.asarray(prep.phi).tolist(), gold["phi"], "phi")              # ... and unchanged in the result
+    th, ph = np.asarray(prep.theta)[:, None], np.asarray(prep.phi)[None, :]
+    e_th = np.cos(th / 2.0) ** 2 * (1.0 + 0.25 * np.cos(ph)) * np.exp(0.3j) + 0j
+    e_ph = 0.3 * np.sin(th) * np.sin(ph) * np.exp(-0.7j) + 0j
+    p_rad = (np.abs(e_th) ** 2 + np.abs(e_ph) ** 2) / (2.0 * 376.730313668)
+    prad = float(np.sum(p_rad * np.sin(th)) * (th[1, 0] - th[0, 0]) * (ph[0, 1] - ph[0, 0]))
+    res = types.SimpleNamespace()
+    if mode in ("full", "weak"):
+        res.E_theta, res.E_phi = [e_th], [e_ph]
+        res.E_norm = [np.sqrt(np.abs(e_th) ** 2 + np.abs(e_ph) ** 2)]
+        res.P_rad = [p_rad * (1e-4 if mode == "weak" else 1.0)]
+        res.Prad, res.Dmax = [prad], [float(4.0 * np.pi * p_rad.max() / prad)]
+    else:
+        res.E_theta, res.E_phi = e_th, e_ph
+    got, dbi = s.legacy_pattern(res, th.size, ph.size)
+    assert dbi is gold["is_dBi"] and list(got.shape) == gold["shape"]
+    sub = gold["sub"]
+    assert np.allclose(got[::sub[0], ::sub[1]], np.asarray(gold["intensity_sub"]), rtol=0, atol=1e-9)
+    assert abs(got.sum() - gold["sum"]) <= 1e-9 * max(1.0, abs(gold["sum"])) and abs((got * got).sum() - gold["sum_sq"]) <= 1e-9 * gold["sum_sq"]
+    # the reference hands DEGREES to CalcNF2FF (openems.py:299-300)
+    c = gold["calc_calls"][0]
+    assert c["ntheta"] == 91 and c["nphi"] == 181 and c["theta_first_last"] == [0.0, 180.0] and c["phi_first_last"] == [0.0, 360.0]
+    assert c["center"] == [0.0, 0.0, 0.001]
+
+
+def test_legacy_run_hands_degrees_to_calcnf2ff_and_returns_radians():
+    """run_prepared_hip on a legacy Prepared whose engine objects are recording fakes: same CalcNF2FF arguments as the
+    reference's (fixture above), result theta / phi in radians, P_rad branch -> dBi."""
+    import types
+    s = pkg("solver_fdtd_hip")
+    prep = s.prepare_hip_patch(_params())
+    seen = {}
+
+    class FakeNF:
+        def can_evaluate(self, f):
+            return True
+
+        def CalcNF2FF(self, sim_path, freq, theta, phi, center=None, **kw):
+            seen.update(freq=freq, theta=np.asarray(theta), phi=np.asarray(phi), center=np.asarray(center))
+            th, ph = np.deg2rad(theta)[:, None], np.deg2rad(phi)[None, :]
+            e = np.cos(th / 2.0) ** 2 * (1.0 + 0.25 * np.cos(ph)) + 1e-3
+            p = e ** 2
+            prad = float(np.sum(p * np.sin(th)) * (th[1, 0] - th[0, 0]) * (ph[0, 1] - ph[0, 0]))
+            return types.SimpleNamespace(E_norm=[e], Dmax=[4 * np.pi * p.max() / prad], P_rad=[p], Prad=[prad], freq=[freq])
+
+    class FakeFDTD:
+        stats = types.SimpleNamespace(steps=1, seconds=1.0, mcells_per_s=1.0, energy_db=-60.0)
+        sim = types.SimpleNamespace(dt=1e-12, grid=types.SimpleNamespace(ncells=8, shape=(2, 2, 2)))
+
+        def Run(self, sim_path, verbose=0, cleanup=False):
+            seen["run"] = (verbose, cleanup)
+
+    prep.FDTD, prep.nf, prep.port = FakeFDTD(), FakeNF(), None
+    r = s.run_prepared_hip(prep, frequency_hz=2.45e9, verbose=0)
+    assert r.ok, r.message
+    assert seen["theta"][0] == 0.0 and seen["theta"][-1] == 180.0 and seen["phi"][-1] == 360.0 and seen["theta"].size == 91
+    assert np.allclose(seen["center"], [0, 0, 1e-3]) and seen["freq"] == 2.45e9 and seen["run"] == (0, False)
+    assert r.theta[-1] == np.pi and r.phi[-1] == 2 * np.pi and r.intensity.shape == (91, 181) and r.is_dBi
+    assert abs(r.intensity.max() - 10 * np.log10(r.Dmax)) < 1e-9
+
+
 def test_never_raises_returns_ok_false():
     s = pkg("solver_fdtd_hip")
     r = s.prepare_hip_microstrip_multi_3d([])

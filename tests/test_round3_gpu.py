@@ -1,0 +1,223 @@
+"""GPU tests added in round 3: the legacy plugin variant run on the GPU against the oracle, the self-healing step
+schedule, the deterministic energy sum, Mur on a 5-node-wide grid, loop-back timing slabs at the ends of a decomposition,
+uneven (cost-weighted) and mixed-schedule slabs, link / schedule introspection, the far-field frequency rules."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+from helpers import patch_sim, seeded_fields, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _params():
+    P = pkg("params").PatchAntennaParams
+    return P.from_user_units(frequency_ghz=2.45, er=4.3, h_mm=1.6, loss_tangent=0.02)
+
+
+def test_legacy_variant_gpu_vs_oracle(hip_lib, oracle_lib, tmp_path):
+    """prepare_hip_patch + run_prepared_hip(variant "legacy") — substrate and ground filling
+    the box into the CPML layers ([3]*6), radian theta / phi (91 x 181), the attribute-sniffing conversion
+    (solver_fdtd_openems.py:271-411) — on the GPU and on the oracle: same grid, same S11, patterns within 1e-3."""
+    s = pkg("solver_fdtd_hip")
+    res = []
+    for lib, tag in ((hip_lib, "gpu"), (oracle_lib, "cpu")):
+        prep = s.prepare_hip_patch(_params(), work_dir=str(tmp_path / tag), lib=lib)
+        assert prep.ok, prep.message
+        assert prep.variant == "legacy" and prep.FDTD.NrTS == 60000 and prep.FDTD.EndCriteria == 1e-5
+        prep.FDTD.NrTS = 1500
+        r = s.run_prepared_hip(prep, frequency_hz=2.45e9, verbose=0)
+        assert r.ok, r.message
+        res.append((r, prep))
+    (g, pg), (c, pc) = res
+    assert g.stats["grid"] == c.stats["grid"] and g.stats["steps"] == c.stats["steps"] == 1500
+    assert pg.FDTD.sim.bc.kinds == ("CPML",) * 6
+    assert g.is_dBi and g.intensity.shape == (91, 181) and g.theta[-1] == np.pi and abs(g.phi[-1] - 2 * np.pi) < 1e-15
+    assert abs(g.intensity.max() - 10 * np.log10(g.Dmax)) < 1e-9       # the P_rad / Prad branch: max directivity = Dmax
+    lin = lambda d: 10.0 ** (np.asarray(d) / 10.0)
+    assert rel_l2(lin(g.intensity), lin(c.intensity)) < 1e-3
+    assert rel_l2(g.s11, c.s11) < 1e-3 and rel_l2(g.port_u, c.port_u) < 1e-6
+    assert abs(g.Dmax - c.Dmax) < 1e-3 * c.Dmax
+    assert g.f_pattern == 2.45e9                                          # evaluated where the caller asked
+
+
+def test_far_field_frequency_rules(hip_lib, tmp_path):
+    """Default: every variant evaluates the far field at frequency_hz (what the reference effectively does — its
+    resonance search, microstrip.py:407-433, is unreachable).  Opt-in resonance rule with running-DFT faces at
+    caller-named frequencies: falls back to frequency_hz instead of failing."""
+    s = pkg("solver_fdtd_hip")
+    p = _params()
+    prep = s.prepare_hip_microstrip_patch(p, feed_direction=s.FeedDirection.NEG_X, boundary="MUR", work_dir=str(tmp_path / "a"))
+    assert prep.ok and prep.pattern_at_resonance is None
+    prep.FDTD.NrTS = 9000
+    r = s.run_prepared_hip(prep, frequency_hz=p.frequency_hz, verbose=0)
+    assert r.ok, r.message
+    assert r.s11_dB.min() < -10.0 and r.f_res != p.frequency_hz        # a dip exists, and still:
+    assert r.f_pattern == p.frequency_hz
+    prep = s.prepare_hip_microstrip_patch(p, feed_direction=s.FeedDirection.NEG_X, boundary="MUR", work_dir=str(tmp_path / "b"),
+                                          nf2ff_mode="dft", nf2ff_freqs=[p.frequency_hz])
+    prep.FDTD.NrTS = 9000
+    prep.pattern_at_resonance = True
+    r2 = s.run_prepared_hip(prep, frequency_hz=p.frequency_hz, verbose=0)
+    assert r2.ok, r2.message
+    assert r2.f_res == r.f_res and r2.f_pattern == p.frequency_hz
+    assert rel_l2(10.0 ** (r2.intensity / 20), 10.0 ** (r.intensity / 20)) < 1e-3     # recorder == running DFT at the same frequency
+
+
+def test_schedule_timeout_heals_itself(hip_lib, monkeypatch):
+    """A flag wait of the one-launch schedule that times out (test hook: at step 37 the H blocks wait for a flag value
+    nobody publishes, limit 20 us) -> the C ABI reports FDTD_E_DEVICE and clears the error word; Simulation.run rebuilds
+    the context under the two-launch schedule and repeats the run from the initial state: same result as a DIRECT run."""
+    capi = pkg("_capi")
+    ref = patch_sim(64, 60, 36, nr_ts=300)
+    e = ref.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT)
+    st_ref = ref.run(check_every=100)
+    f_ref = e.fields()
+    monkeypatch.setenv("FDTD_WF_FAULT_STEP", "37")
+    s = patch_sim(64, 60, 36, nr_ts=300)
+    eng = s.build(hip_lib)
+    assert eng.schedule_info()["launches_per_timestep"] == 1
+    with pytest.raises(capi.FdtdError, match="wavefront schedule"):
+        eng.run(100)
+    eng.run(10)                                   # the error word was cleared: the context is usable (its fields are not)
+    s = patch_sim(64, 60, 36, nr_ts=300)
+    s.build(hip_lib)
+    logs = []
+    st = s.run(check_every=100, log=logs.append)
+    assert st.schedule_fallback and "wavefront schedule" in st.schedule_fallback and logs
+    assert st.steps == 300 and s.engine.schedule_info()["launches_per_timestep"] == 2
+    assert np.array_equal(s.engine.fields(), f_ref) and st.energy_db == st_ref.energy_db
+    u, i = s.port_series()[0]
+    u0, i0 = ref.port_series()[0]
+    assert np.array_equal(u, u0) and np.array_equal(i, i0)
+
+
+def test_energy_sum_is_reproducible(hip_lib, oracle_lib):
+    """fdtd_energy: per-block partials added in block order by the last block (no atomicAdd on doubles): identical bits
+    from call to call and from context to context; equal to the oracle's sums to 1e-12."""
+    vals = []
+    for _ in range(2):
+        s = patch_sim(53, 47, 31, nr_ts=120)
+        e = s.build(hip_lib)
+        seeded_fields(e, 3)
+        e.run(120)
+        vals.append([e.energy() for _ in range(3)])
+    flat = [v for run in vals for v in run]
+    assert all(v == flat[0] for v in flat)
+    s = patch_sim(53, 47, 31, nr_ts=120)
+    e = s.build(oracle_lib)
+    seeded_fields(e, 3)
+    e.run(120)
+    assert np.allclose(flat[0], e.energy(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("shape", [(5, 20, 18), (6, 20, 18), (20, 5, 18), (20, 18, 5)])
+def test_mur_on_five_node_wide_grids(hip_lib, oracle_lib, shape):
+    """Mur faces on a grid 5 nodes wide: along x both inner nodes (1 and 3) lie in ONE thread's four cells, so the post
+    pass fused into update_E (one x pair of S values per thread) must not be taken there; 6 wide it is."""
+    capi, const = pkg("_capi"), pkg("constants")
+    from opbuild_cases import random_scene
+    grid, eps, kap, pec, _ = random_scene(5, shape, False, 3, n_lumped=0, pec_frac=0.0)
+    dt = grid.courant_dt()
+    nx, ny, nz = grid.shape
+    n = 90
+    out = []
+    for lib in (hip_lib, oracle_lib):
+        e = capi.Engine(lib, nx, ny, nz, dt, max_steps=n + 8)
+        eco = pkg("ecoperator")
+        emet, hmet = eco.pack_metric_tables(*eco.metric_lists(grid, dt), grid)
+        e.build_operator(grid.d, eps, kap, pec, const.EPS0, eco.lumped_overrides(grid, eps, kap, pec, dt, []), emet, hmet)
+        coeff = []
+        for f in range(6):
+            l = grid.lines[f // 2]
+            d = (l[-1] - l[-2]) if f % 2 else (l[1] - l[0])
+            coeff.append((const.C0 * dt - d) / (const.C0 * dt + d))
+        e.set_mur([1] * 6, coeff)
+        t = np.arange(n) * dt
+        e.set_signal(np.sin(2 * np.pi * 8e9 * t) * np.exp(-((t - 30 * dt) / (12 * dt)) ** 2))
+        i, j, k = nx // 2, ny // 2, nz // 2
+        comp = int(np.argmin(shape))                       # drive the component along the thin axis
+        e.add_source(np.array([(k * ny + j) * nx + i], np.int64), np.array([comp], np.int8), np.array([1.0], np.float32))
+        seeded_fields(e, 11, 1e-4)
+        e.run(n)
+        out.append(e.fields())
+    assert np.abs(out[1]).max() > 0 and np.array_equal(out[0], out[1]), f"rel L2 {rel_l2(out[0], out[1]):.3e}"
+
+
+def test_loopback_slabs_at_both_ends_of_a_decomposition(hip_lib):
+    """tools/slab_balance.py times every slab of a decomposition alone on one GPU: FDTD_FLAG_LOOPBACK + its own blob for
+    both neighbours.  Rank 0, an interior rank and the last rank all step (no halo wait times out), under both schedules;
+    without the flag an end rank refuses a blob for the neighbour it does not have."""
+    capi = pkg("_capi")
+    world = 4
+    for flags in (capi.FLAG_KERNEL_DIRECT, capi.FLAG_KERNEL_WAVEFRONT):
+        for rank in (0, 2, world - 1):
+            s = patch_sim(56, 52, 48, nr_ts=80, nf2ff=False)
+            e = s.build(hip_lib, rank=rank, world=world, flags=flags | capi.FLAG_LOOPBACK)
+            blob = e.p2p_export()
+            e.p2p_attach(blob, blob)
+            seeded_fields(e, rank)
+            e.run(60)
+            assert e.step == 60 and e.schedule_info()["transport"] == "p2p"
+            li = e.p2p_link_info(1)
+            assert li["same_device"] and li["mapping"] == "same-process" and li["device"] == 0
+    s = patch_sim(56, 52, 48, nr_ts=80, nf2ff=False)
+    e = s.build(hip_lib, rank=0, world=world)
+    blob = e.p2p_export()
+    with pytest.raises(capi.FdtdError, match="exactly its existing neighbours"):
+        e.p2p_attach(blob, blob)
+
+
+def _attach_p2p(engs):
+    blobs = [e.p2p_export() for e in engs]
+    for r, e in enumerate(engs):
+        e.p2p_attach(blobs[r - 1] if r > 0 else None, blobs[r + 1] if r + 1 < len(engs) else None)
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_cost_weighted_slabs_and_mixed_schedules_equal_one_slab(hip_lib, world):
+    """The cost-weighted z-partition (end ranks own fewer planes: all z-CPML planes are theirs) on the mailbox transport,
+    the slabs stepping under DIFFERENT schedules (one launch per timestep on the even ranks, two on the odd ones — what
+    AUTO does when only some slabs of an uneven partition pass its block-count threshold): bit-identical to one slab."""
+    capi, simm = pkg("_capi"), pkg("simulation")
+    s1 = patch_sim(56, 52, 60, cpml_cells=10, nr_ts=220)
+    e1 = s1.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT)
+    sims = [patch_sim(56, 52, 60, cpml_cells=10, nr_ts=220) for _ in range(world)]
+    flags = [capi.FLAG_KERNEL_WAVEFRONT if r % 2 == 0 else capi.FLAG_KERNEL_DIRECT for r in range(world)]
+    engs = [s.build(hip_lib, rank=r, world=world, flags=flags[r]) for r, s in enumerate(sims)]
+    nks = [e.nk for e in engs]
+    assert sum(nks) == 60 and nks[0] < max(nks) and nks[-1] < max(nks)             # uneven: the end slabs are thinner
+    assert nks != [simm.slab_range(60, world, r)[1] for r in range(world)]
+    assert [e.schedule_info()["launches_per_timestep"] for e in engs] == [0] * world   # not steppable before a transport is attached
+    _attach_p2p(engs)
+    assert [e.schedule_info()["launches_per_timestep"] for e in engs] == [1 if r % 2 == 0 else 2 for r in range(world)]
+    rng = np.random.default_rng(9)
+    for kind in (0, 1):
+        for comp in range(3):
+            g = (1e-3 * rng.standard_normal(e1.local_shape)).astype(np.float32)
+            e1.set_field(kind, comp, g)
+            for e in engs:
+                e.set_field(kind, comp, np.ascontiguousarray(g[e.k0:e.k0 + e.nk]))
+    e1.run(220)
+    for n in (1, 90, 129):
+        capi.run_linked(engs, n)
+    f1, f2 = e1.fields(), np.concatenate([e.fields() for e in engs], axis=2)
+    assert np.abs(f1).max() > 0 and np.array_equal(f1, f2)
+    u1, i1 = s1.port_series()[0]
+    assert rel_l2(sum(s.port_series()[0][0] for s in sims), u1) < 1e-12
+    assert rel_l2(sum(s.port_series()[0][1] for s in sims), i1) < 1e-12
+
+
+def test_schedule_info_tells_the_schedule(hip_lib):
+    capi = pkg("_capi")
+    s = patch_sim(64, 60, 36, nr_ts=10)
+    info = s.build(hip_lib).schedule_info()
+    assert info["launches_per_timestep"] == 1 and info["lag_planes"] == 36 and info["transport"] == "none" and info["xcd_shares_weighted"]
+    assert info["blocks_per_sweep"] > 0 and info["rows_per_strip"] >= 4
+    s = patch_sim(64, 60, 36, nr_ts=10)
+    assert s.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT).schedule_info()["launches_per_timestep"] == 2
+    s = patch_sim(48, 44, 30, boundary="MUR", nr_ts=10)
+    info = s.build(hip_lib).schedule_info()
+    assert info["launches_per_timestep"] == 3 and not info["xcd_shares_weighted"]
+    s = patch_sim(48, 44, 30, boundary="PEC", nr_ts=10)
+    assert s.build(hip_lib).schedule_info()["launches_per_timestep"] == 2     # small grid without CPML: two launches
