@@ -1,39 +1,36 @@
 #!/bin/bash
-# Everything profiles/rNN/ holds for one round, produced ON the GPU box from the repo root:
-#   bash tools/profile_round.sh r02        (writes gpurun_out/r02/, copy what is to be judged into profiles/r02/)
-# 1. the bench line of every BASELINE workload (same box),  2. rocprofv3 --kernel-trace --stats of `python3 bench.py`
-# for NS, C3, C5 (+ the bench line printed under the profiler),  3. HBM-side traffic of NS and C3 from separate --pmc
-# passes (tools/pmc_traffic.py),  4. the per-axis CPML cost A/B (tools/kernel_ab.py),  5. the two schedules on C3-C5.
-set -o pipefail
-R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/${1:-r02}
-mkdir -p $OUT
-cd $R
-for w in NS C2 C3 C4 C5; do
-  extra="--no-hbm-point --no-cpu-baseline"; [ $w = NS ] && extra=""
-  timeout -k 10 300 python3 bench.py --workload $w $extra > $OUT/bench_$w.json 2> $OUT/bench_$w.err || echo "bench $w failed" >&2
-  echo "bench $w done"
+# tools/profile_round.sh <tag>: everything profiles/<tag>/ holds that comes from one box — run ON a GPU box from the repo root:
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r03'
+# Writes under gpurun_out/<tag>/ (copy what is to be judged into profiles/<tag>/).
+set -u
+tag=${1:-r03}
+root=$PWD
+out=$root/gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+# 1. bench lines of every BASELINE workload (the default line first: NS with the C3 point and the CPU baseline)
+python3 bench.py > $out/bench_NS.json 2> $out/bench_NS.err
+for w in C2 C3 C4 C5; do
+  python3 bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-hbm-point > $out/bench_$w.json 2> $out/bench_$w.err
 done
-cd /tmp && export TMPDIR=/tmp
+echo "bench lines done" >&2
+# 2. rocprofv3 kernel traces of the same command (program directly after --)
 for w in NS C3 C5; do
-  rm -rf $OUT/trace_$w
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/trace_$w -- python3 $R/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-hbm-point > $OUT/bench_${w}_under_rocprofv3.json 2> $OUT/trace_$w.err || echo "trace $w failed" >&2
-  python3 $R/tools/rocprof_db_stats.py $(dirname $(ls $OUT/trace_$w/*/*.db | head -1)) > $OUT/kernel_stats_$w.csv
-  rm -rf $OUT/trace_$w
-  echo "trace $w done"
+  d=$out/trace_$w
+  rm -rf $d
+  if [ $w = NS ]; then args="--no-cpu-baseline --no-hbm-point"; else args="--workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-hbm-point"; fi
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $d -- python3 $root/bench.py $args > $out/bench_${w}_under_rocprofv3.json 2> $out/trace_$w.err)
+  python3 tools/rocprof_db_stats.py $(dirname $(find $d -name "*.db" | head -1)) > $out/kernel_stats_$w.csv 2>> $out/trace_$w.err
+  rm -rf $d
+  echo "trace $w done" >&2
 done
-cd $R
-for w in NS C3 C5; do
-  timeout -k 10 600 python3 tools/pmc_traffic.py $w $OUT/pmc_traffic_${w}.json > $OUT/pmc_$w.log 2>&1 || echo "pmc $w failed" >&2
+# 3. PMC traffic (separate passes per counter, tools/pmc_traffic.py)
+for w in NS C2 C3; do
+  python3 tools/pmc_traffic.py $w $out/pmc_traffic_$w.json > /dev/null 2> $out/pmc_$w.err
   rm -rf gpurun_out/pmc_${w}_FETCH_SIZE gpurun_out/pmc_${w}_WRITE_SIZE
-  echo "pmc $w done"
+  echo "pmc $w done" >&2
 done
-timeout -k 10 300 python3 tools/kernel_ab.py NS,C3 CPML,PEC,xCPML,yCPML,zCPML 400 > $OUT/cpml_axis_cost.txt 2>&1
-# 5. same-box A/B of the two schedules on the grids beyond the Infinity Cache: two launches per timestep (flags 1) vs one (flags 5)
-for w in C3 C4 C5; do
-  AB_FLAGS=1 AB_TAG=two_launches timeout -k 10 200 python3 tools/kernel_ab.py $w CPML,PEC 400 >> $OUT/wavefront_ab.txt 2>&1
-  AB_FLAGS=5 AB_TAG=one_launch timeout -k 10 200 python3 tools/kernel_ab.py $w CPML,PEC 400 >> $OUT/wavefront_ab.txt 2>&1
-done
-timeout -k 10 200 python3 tools/plugin_path_timing.py > $OUT/plugin_path_timing_fixed_scene.txt 2>&1
-lscpu | head -20 > $OUT/host_cpu.txt
-echo "all done"
+# 4. per-axis CPML cost and the XCD-share A/B
+python3 tools/kernel_ab.py NS,C3 CPML,PEC,xCPML,yCPML,zCPML 1000 > $out/cpml_axis_cost.txt 2>&1
+lscpu | head -20 > $out/host_cpu.txt
+echo "profile round $tag done" >&2
