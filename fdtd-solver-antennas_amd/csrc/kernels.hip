@@ -468,6 +468,10 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
 // every wave drains its stores (vmcnt(0)), the block meets, ONE lane publishes the flag with an sc1 store; the consumer's
 // polling wave reads the flags with sc1 loads, the block meets, and EVERY load of V is an sc1 load to registers.
 // ------------------------------------------------------------------------------------------------
+#ifdef FDTD_XCD_TRACE
+#define FDTD_XCD_TRACE_MAX 65536
+__device__ unsigned long long g_xcd_trace[2 * FDTD_XCD_TRACE_MAX * 4];   // [step & 1][block][start, end, XCC_ID | E/H << 3 | valid << 4, step]
+#endif
 template <int COEF, bool PML, bool P2P>
 __global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_MINBLOCKS) void k_step(const DevParams p, const long long step, const int lag, const unsigned wf_target,
                                                                         const unsigned nbp, const FastDiv fd_2m, const int down, const unsigned nmain) {
@@ -514,8 +518,20 @@ __global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_M
   // P2P (mailbox halo transport, upwards only): E of plane 0 — the first blocks of the launch — takes its k-1 neighbours from
   // the lower rank's mailbox and pushes its result down; H of the top plane — the last H blocks — takes k+1 from the upper
   // rank's mailbox (that rank's E blocks of plane 0 are the first of ITS launch) and pushes its result up.
+#ifdef FDTD_XCD_TRACE   // diagnostic builds only (tools/xcd_trace.py): every block leaves {start, end (its first wave), XCC_ID, E/H} in its own
+  // 32-byte slot of a per-launch table (two tables, alternating with the step): plain stores, no atomics, no extra barrier
+  const unsigned long long t_begin = wall_clock64();
+#endif
   if (!is_h) body_E<COEF, PML, true, P2P, true>(p, (int)strip, k, pb, step, s_lut, s_psi, s_xc, s_src, wf_target);
   else body_H<COEF == 0, PML, P2P, true>(p, (int)strip, k, pb, step, s_psi, s_xc, wf_target);
+#ifdef FDTD_XCD_TRACE
+  if (threadIdx.x == 0 && b < FDTD_XCD_TRACE_MAX) {
+    unsigned xid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
+    unsigned long long* const slot = g_xcd_trace + ((size_t)(step & 1) * FDTD_XCD_TRACE_MAX + b) * 4;
+    slot[0] = t_begin; slot[1] = wall_clock64(); slot[2] = (xid & 7u) | (is_h ? 8u : 0u) | 16u; slot[3] = (unsigned long long)step;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1138,3 +1154,16 @@ void launch_energy(fdtd_ctx* c, hipStream_t s) {
   hipLaunchKernelGGL(k_energy, dim3(ENERGY_BLOCKS), dim3(FDTD_BLOCK), 0, s, c->p, c->d_energy, c->d_energy + 2,
                      reinterpret_cast<unsigned*>(c->d_energy + 2 + 2 * ENERGY_BLOCKS));
 }
+
+#ifdef FDTD_XCD_TRACE
+// diagnostic builds only: fetch the per-block trace table of the launch of `step` (the last two launches are kept)
+extern "C" int fdtd_debug_xcd_trace(long long step, unsigned long long* out) {
+  if (step < 0) {   // clear both tables
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_xcd_trace)) != hipSuccess) return -3;
+    return hipMemset(q, 0, sizeof(unsigned long long) * 2 * FDTD_XCD_TRACE_MAX * 4) == hipSuccess ? 0 : -3;
+  }
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xcd_trace), (size_t)FDTD_XCD_TRACE_MAX * 4 * sizeof(unsigned long long),
+                             (size_t)(step & 1) * FDTD_XCD_TRACE_MAX * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -33,6 +33,8 @@ def main():
             except AttributeError:
                 setattr(raw, name, raw["fdtd_version"])
         lib = capi.bind(raw)
+        capi._hip_lib = lib                      # the workload builders (C4, C5 go through solver_fdtd_hip) load "the" library
+        os.environ.pop("FDTD_HIP_LIB_DIR", None)
     else:
         lib = capi.load_hip_library()
     for name in names:
