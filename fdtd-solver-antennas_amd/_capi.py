@@ -413,7 +413,7 @@ class Engine:
         return {"launches_per_timestep": int(a[0]), "lag_planes": int(a[1]), "rows_per_strip": int(a[2]),
                 "blocks_per_sweep": int(a[3]),
                 "transport": ("none", "p2p", "rccl", "linked", "external")[int(a[4])] if 0 <= a[4] <= 4 else None,
-                "xcd_shares_weighted": bool(a[5])}
+                "xcd_shares_weighted": bool(a[5]), "xcd_adaptations": int(a[6]), "timesteps_per_launch_max": int(a[7])}
 
     def comm_nranks(self) -> int:
         """Ranks of the RCCL communicator attached to this context (0: none)."""

@@ -185,9 +185,11 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   if (getenv("FDTD_MUR_UNFUSED")) c->mur_fuse_post = false;   // experiments: the Mur post pass as a launch of its own
   if (const char* v = getenv("FDTD_WAVEFRONT")) c->wf_mode = atoi(v) ? 1 : 0;
   if (const char* v = getenv("FDTD_WF_LAG")) c->wf_lag = std::max(0, std::min(4096, atoi(v)));
+  if (const char* v = getenv("FDTD_WF_MULTI")) c->wf_multi = std::max(1, std::min(4096, atoi(v)));   // timesteps per launch at most (1: one launch per timestep)
   if (const char* v = getenv("FDTD_OCC_H")) c->occ_h = std::max(0, std::min(16, atoi(v)));
   if (const char* v = getenv("FDTD_WF_FAULT_STEP")) c->wf_fault_step = atoll(v);   // test hook: the H blocks of that step wait for flags nobody sets (bounded wait -> error word)
   if (const char* v = getenv("FDTD_XCD_BALANCE")) c->xcd_balance = atoi(v) != 0;        // experiments: 0 = XCD shares of equal length
+  if (const char* v = getenv("FDTD_XCD_ADAPT")) c->xcd_adapt = atoi(v) != 0;            // 0 = the cost model's cuts, never the measured ones
   if (const char* v = getenv("FDTD_XCD_WY")) c->xw_y = std::max(0.0, std::min(4.0, atof(v)));
   if (const char* v = getenv("FDTD_XCD_WZ")) c->xw_z = std::max(0.0, std::min(4.0, atof(v)));
   if (const char* v = getenv("FDTD_XCD_WYZ")) c->xw_yz = std::max(0.0, std::min(4.0, atof(v)));
@@ -207,7 +209,9 @@ void fdtd_destroy(fdtd_ctx* c) {
   for (int n = 0; n < 6; ++n) hipFree(c->fieldbase[n]);
   hipFree(c->vv); hipFree(c->vi); hipFree(c->ii); hipFree(c->iv); hipFree(c->ecls); hipFree(c->lut); hipFree(c->met);
   hipFree(c->cpcoef); hipFree(c->xc_tab);
+  hipFree(c->xstamp);
   hipFree(c->wf_flags); hipFree(c->wf_err); hipFree(c->wf_flagsH); hipFree(c->wf_prb_sp); hipFree(c->wf_prb_blk); hipFree(c->wf_prb_rng);
+  hipFree(c->wf_prbV_sp); hipFree(c->wf_prb_done);
   for (int n = 0; n < 12; ++n) hipFree(c->psi[n]);
   for (int f = 0; f < 6; ++f) { hipFree(c->mur[f].st[0]); hipFree(c->mur[f].st[1]); }
   hipFree(c->d_mur);
@@ -715,6 +719,7 @@ static bool sources_fusable(const fdtd_ctx* c) {
 struct ProfEvents {
   std::vector<hipEvent_t> e0, e1, h0, h1;
   hipEvent_t t0 = nullptr, t1 = nullptr;
+  int launches = -1;   // main launches of the profiled run when they are not one per timestep (several timesteps per launch)
 };
 
 // One leapfrog step = two main launches.  Without Mur faces the soft sources are injected inside update_E
@@ -828,16 +833,38 @@ static void p2p_prime_if_needed(fdtd_ctx* c);
 static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   HIPCK(c, hipSetDevice(c->d.device));
   hipStream_t s = c->stream;
-  for (int n = 0; n < nsteps; ++n) {
+  // the last launch of a call of at least 16 timesteps is a calibration launch of the XCD shares (kernels.hip: xcd_adapt) —
+  // often in the first eight calls of a context, every eighth call after that
+  const bool calibrate = !pe && nsteps >= 16 && c->d.world == 1 && (c->xcd_adapt_calls < 8 || (c->xcd_adapt_calls & 7) == 0);
+  if (!pe && nsteps >= 16) c->xcd_adapt_calls++;
+  // Cache-resident single slabs: SEVERAL timesteps per launch (k_step<.., MULTI>) — up to the next timestep whose NF2FF faces
+  // are sampled (a launch of its own reads them), the calibration launch on its own.
+  const int multi = wf_multi_max(c);
+  const bool sampling = (c->nfreq || c->recorder) && c->nbox && c->every > 0;
+  int launches = 0;
+  for (int n = 0; n < nsteps;) {
     p2p_prime_if_needed(c);
-    if (pe) { c->kev0 = pe->e0[n]; c->kev1 = pe->e1[n]; }
-    int r = launch_step_wf(c, c->step, s);
+    int chunk = 1;
+    if (multi > 1) {
+      chunk = std::min(multi, nsteps - n);
+      if (sampling) {   // ... so that the sampled timestep (a multiple of `every`) is the launch's last
+        const long long next = (c->step + c->every - 1) / c->every * c->every;
+        chunk = (int)std::min<long long>(chunk, next - c->step + 1);
+      }
+      if (calibrate && n + chunk == nsteps && chunk > 1) chunk -= 1;
+    }
+    if (pe) { c->kev0 = pe->e0[launches]; c->kev1 = pe->e1[launches]; }
+    if (calibrate && n + chunk == nsteps && chunk == 1) { int ra = xcd_stamp_arm(c, s); if (ra) return ra; }
+    int r = launch_step_wf(c, c->step, s, chunk);
     c->kev0 = c->kev1 = nullptr;
     if (r) return r;
-    launch_dft(c, FDTD_KIND_V, c->step, s);
-    launch_dft(c, FDTD_KIND_I, c->step, s);
-    c->step++;
+    c->step += chunk;
+    launch_dft(c, FDTD_KIND_V, c->step - 1, s);
+    launch_dft(c, FDTD_KIND_I, c->step - 1, s);
+    n += chunk;
+    ++launches;
   }
+  if (pe) pe->launches = launches;
   HIPCK(c, hipGetLastError());
   return FDTD_OK;
 }
@@ -932,7 +959,8 @@ int fdtd_run(fdtd_ctx* c, int nsteps) {
   HIPCK(c, hipStreamSynchronize(c->stream));
   HIPCK(c, hipStreamSynchronize(c->comm_stream));
   if (c->p.p2p) { r = p2p_check(c); if (r) return r; }
-  return wf_check(c);
+  if ((r = wf_check(c))) return r;
+  return xcd_adapt(c);     // (a no-op unless the call's last launch was a calibration launch of the XCD shares)
 }
 
 int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
@@ -975,16 +1003,17 @@ int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
     // Every main launch carried its own start / stop events (hipExtLaunchKernelGGL), which take the dispatch's begin
     // and end timestamps — the interval a kernel trace reports, no event-packet time inside, nothing to calibrate away.
     double se = 0, sh = 0;
-    for (int n = 0; n < nsteps; ++n) {
+    const int nl = pe.launches >= 0 ? pe.launches : nsteps;
+    for (int n = 0; n < nl; ++n) {
       if (hipEventElapsedTime(&ms, pe.e0[n], pe.e1[n]) == hipSuccess) se += ms;
-      if (hipEventElapsedTime(&ms, pe.h0[n], pe.h1[n]) == hipSuccess) sh += ms;
+      if (pe.launches < 0 && hipEventElapsedTime(&ms, pe.h0[n], pe.h1[n]) == hipSuccess) sh += ms;
     }
     (void)hipGetLastError();
     out->ms_event_overhead = 0.0;
-    out->ms_update_e = se / nsteps;
+    out->ms_update_e = se / nsteps;             // per TIMESTEP (launches of several timesteps: their durations summed, over the timesteps)
     out->ms_update_h = sh / nsteps;
     out->fused = wavefront_active(c) ? 1 : 0;   // 1: ms_update_e is the one launch of a whole timestep, ms_update_h = 0
-    out->launches_e = nsteps; out->launches_h = out->fused ? 0 : nsteps;
+    out->launches_e = nl; out->launches_h = out->fused ? 0 : nsteps;
   }
   destroy_all();
   if (r) return r;
@@ -1369,6 +1398,8 @@ int fdtd_schedule_info(fdtd_ctx* c, int32_t info[8]) {
   info[3] = c->d.nk * c->p.nstrips * c->p.nbs;
   info[4] = !multi ? 0 : c->p.p2p ? 1 : c->comm ? 2 : (c->link_lo || c->link_hi) ? 3 : 4;
   info[5] = (c->xcd_balance && c->have_cpml) ? 1 : 0;
+  info[6] = c->xcd_adapt_done;
+  info[7] = wf ? wf_multi_max(c) : 0;
   return FDTD_OK;
 }
 

@@ -88,6 +88,9 @@ struct DevParams {
   // main part.  ps / pm: the same for the blocks of ONE plane (k_step beyond the Infinity Cache: plane groups)
   unsigned xs[9], xgrid;
   unsigned ps[9], pm;
+  // calibration launches of k_step only (else null): block b leaves the wall clock at its end in xstamp[b], blocks 0..7 also
+  // at their start in xstamp[xstamp_n + b] — the host turns them into per-XCD finish times and re-cuts the shares (xcd_adapt)
+  unsigned long long* xstamp; unsigned xstamp_n;
   // P2P mailbox halo transport (in-kernel pushes over xGMI / peer mappings; no streams, events or RCCL in the step loop).
   // Mailbox layout (one allocation per context, zero at start): [E: 2 parities][2 comps][2 * plane] words — 8-byte granules
   // {value, tag} — then the same for H, then 64 control words.  mb_in_*: my own mailbox; mb_out_*: the neighbour's (peer
@@ -104,6 +107,9 @@ struct DevParams {
   // ... and the probes of a step as the LAST blocks of its launch: H blocks of strip-planes that hold I-probe cells store
   // write-through and publish flags of their own (wf_flagsH, same indexing); probe q waits for the blocks wf_prb_blk[wf_prb_rng[q]]
   unsigned* wf_flagsH; const int* wf_prb_sp; const int* wf_prb_blk; const int2* wf_prb_rng;
+  // several timesteps per launch: strip-planes that hold V-probe cells (wf_prb_sp: I-probe cells), and per probe the flag value
+  // of the last timestep whose probe block has read its cells (the next timestep's blocks wait for it before they overwrite them)
+  const int* wf_prbV_sp; unsigned* wf_prb_done;
   int nt;                    // 1: non-temporal stores for the field outputs (working set beyond the Infinity Cache)
   // fused soft sources (update_E) and probes (extra block of update_E / update_H)
   const int2* src_rng;       // [nk][nstrips]: range into src_ids of the sources inside that strip-plane
@@ -142,6 +148,8 @@ struct fdtd_ctx {
   unsigned wf_epoch = 0;         // flag value of the last wavefront launch
   long long wf_fault_step = -1;  // test hook ($FDTD_WF_FAULT_STEP): at that step the H blocks wait for a flag value nobody publishes
   unsigned* wf_flagsH = nullptr; int* wf_prb_sp = nullptr; int* wf_prb_blk = nullptr; int2* wf_prb_rng = nullptr;
+  int* wf_prbV_sp = nullptr; unsigned* wf_prb_done = nullptr;
+  int wf_multi = 64;             // timesteps per launch at most (cache-resident single slabs without Mur faces); 1 = one launch per timestep; $FDTD_WF_MULTI
   bool wf_prb_dirty = true;      // probe tables of the wavefront launch need rebuilding (a probe was added)
   std::vector<int> h_prb_off[FDTD_MAX_PROBES];   // local offsets of every probe's cells (host copy)
   int occ_wf = 0;                // cap on resident blocks per CU of k_step (0: none); $FDTD_OCC_WF
@@ -151,6 +159,16 @@ struct fdtd_ctx {
   bool xcd_balance = true;
   double xw_y = 0.45, xw_z = 0.45, xw_yz = 0.35;
   struct XcdShare { unsigned xs[9]; unsigned grid; };
+  // ... and MEASURED: the eight shares are cut at cumulative cost fractions xfrac (k_step, all E blocks then all H blocks; pfrac:
+  // k_step in plane groups, never adapted), 1/8 each to begin with; after a run the finish times of the eight XCD shares in its
+  // last launch move them (api.hip: xcd_adapt) — the XCDs of one chip do not run equally fast, and not the same ones
+  // are slow on every chip (profiles/r03/xcd_trace*.txt).  $FDTD_XCD_ADAPT=0 keeps the model's cuts.
+  bool xcd_adapt = true;
+  double xfrac[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
+  double pfrac[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
+  int xcd_adapt_calls = 0, xcd_adapt_done = 0;   // fdtd_run calls seen / adaptations made
+  unsigned long long* xstamp = nullptr; size_t xstamp_cap = 0;   // device table of the calibration launch
+  unsigned xstamp_grid = 0; int xstamp_mode = 0;   // main blocks of the stamped launch; 1: all E then all H, 2: plane groups
   std::map<std::pair<int, int>, XcdShare> xcd_cache;   // (first plane, planes) of a launch -> its shares
   float *vv = nullptr, *vi = nullptr, *ii = nullptr, *iv = nullptr;
   uint8_t* ecls = nullptr;
@@ -213,7 +231,8 @@ int upload_metric_tables(fdtd_ctx* c, const float* emet, const float* hmet);
 void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool fused, bool probe_block, hipStream_t s);
 void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s, bool mur_pre = false);
 // one launch = E and H half-step of all planes (single slab, no Mur, fusable sources); probes are sampled by launch_probes
-int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s);
+int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s, int nsteps = 1);   // nsteps > 1: that many timesteps in ONE launch
+int wf_multi_max(const fdtd_ctx* c);   // timesteps one launch may hold (1: this context steps one timestep per launch)
 int wf_lag_for(const fdtd_ctx* c);
 void launch_p2p_prime(fdtd_ctx* c, hipStream_t s);   // p2p transport, before step 0: initial Ix, Iy of the top plane -> upper rank's mailbox
 void launch_probes(fdtd_ctx* c, long long step, hipStream_t s);   // V- and I-probes of `step` in one launch (stand-alone form)
@@ -225,3 +244,5 @@ void launch_rec_dft(const float* rec, long npts, int ns, int nfreq, const double
 void launch_energy(fdtd_ctx* c, hipStream_t s);
 void choose_tiling(fdtd_ctx* c);
 void xcd_shares_reset(fdtd_ctx* c);   // after the CPML layers or the tiling changed
+int xcd_stamp_arm(fdtd_ctx* c, hipStream_t s);   // the next k_step launch leaves its blocks' end times (calibration)
+int xcd_adapt(fdtd_ctx* c);              // after that launch has finished: per-XCD finish times -> new share fractions

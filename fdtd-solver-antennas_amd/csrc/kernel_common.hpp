@@ -193,8 +193,14 @@ __device__ __forceinline__ void wf_poll(const DevParams& p, const unsigned* f, c
 // Probe q of step `step` as one of the LAST blocks of the step's launch: wait for the blocks that own its cells (E flags for
 // a V-probe, H flags for an I-probe: those H blocks stored write-through), read the cells with device-scope loads, reduce
 // with probe_block's tree (identical sums).
+// MULTI (several timesteps per launch): when the cells have been read the block says so (wf_prb_done[q] = target) — the blocks
+// that overwrite probe cells in the NEXT timestep of the launch wait for that.
+template <bool MULTI = false>
 __device__ __forceinline__ void wf_probe_tail(const DevParams& p, const int q, const long long step, const unsigned target, double* red) {
-  if (step < 0 || step >= p.max_steps) return;
+  if (step < 0 || step >= p.max_steps) {
+    if (MULTI && threadIdx.x == 0) __hip_atomic_store(p.wf_prb_done + q, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   const DevProbe pr = p.probes[q];
   const int2 rng = p.wf_prb_rng[q];
   const unsigned* flags = pr.kind == FDTD_KIND_V ? p.wf_flags : p.wf_flagsH;
@@ -212,7 +218,39 @@ __device__ __forceinline__ void wf_probe_tail(const DevParams& p, const int q, c
     if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) pr.series[step] = red[0];
+  if (threadIdx.x == 0) {
+    pr.series[step] = red[0];
+    if (MULTI) __hip_atomic_store(p.wf_prb_done + q, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (every thread's loads were consumed before the first barrier above)
+  }
+}
+// A block that is about to overwrite cells a probe of `kind` samples: wait until the probe blocks of the previous timestep
+// have read them (one lane per probe; FDTD_MAX_PROBES <= 64)
+__device__ __forceinline__ void wf_wait_probes(const DevParams& p, const int kind, const unsigned target) {
+  if ((int)threadIdx.x < p.nprobe && p.probes[threadIdx.x].kind == kind) wf_poll(p, p.wf_prb_done + threadIdx.x, target);
+  __syncthreads();
+}
+// E block (k, strip, pb) of a LATER timestep of a multi-step launch: wait for the H blocks of the previous timestep that wrote
+// the I values it reads and read the V values it overwrites (the same set): threads t - P4 - 1 .. t + 255 of the strip-plane
+// (its own cells, the row below, the element left of a group) — running into the previous strip's last rows at a strip's
+// start — and the same block of plane k - 1.  The mirror image of wf_wait below.
+__device__ __forceinline__ void wf_wait_back(const DevParams& p, const int k, const int strip, const int pb, const unsigned target) {
+  if (threadIdx.x < 64u) {
+    const int hop = 1 + p.P4 / FDTD_BLOCK;
+    const int first = pb * FDTD_BLOCK - p.P4 - 1;                 // first strip-linear thread whose data is read (may be negative)
+    const int t = (int)threadIdx.x;
+    const unsigned* f = nullptr;
+    const size_t row = ((size_t)k * p.nstrips + strip) * p.nbs;
+    if (t <= hop) {                                               // same strip-plane: this block and the ones before it
+      if (pb - t >= 0 && (pb - t + 1) * FDTD_BLOCK - 1 >= first) f = p.wf_flagsH + row + pb - t;
+    } else if (t <= 2 * hop + 1) {                                // previous strip's last blocks (always a full strip)
+      const int q = t - hop - 1, Tp = p.tys * p.P4, lastb = (Tp - 1) / FDTD_BLOCK;
+      if (first < 0 && strip > 0 && lastb - q >= 0 && min((lastb - q + 1) * FDTD_BLOCK, Tp) - 1 >= Tp + first) f = p.wf_flagsH + row - p.nbs + lastb - q;
+    } else if (t == 2 * hop + 2) {                                // plane below
+      if (k > 0) f = p.wf_flagsH + row - (size_t)p.nstrips * p.nbs + pb;
+    }
+    if (f) wf_poll(p, f, target);
+  }
+  __syncthreads();
 }
 // H block (k, strip, pb): wait for the E blocks whose output it reads / whose input it overwrites.  Threads t .. t+255 of
 // the strip-plane read rows j and j+1 (thread t + P4) and the element right of their group (thread t + 1): strip-linear
@@ -353,6 +391,32 @@ __device__ __forceinline__ void glds16o(const float* base, const unsigned e, con
 __device__ __forceinline__ void sto4(float* base, const unsigned e, const float4& v) {
   *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + (e << 2)) = v;
 }
+// Device-scope (sc1) forms for launches of several timesteps, where a psi value written in one timestep is read in the next by
+// another workgroup — the same cells, but wherever the dispatcher put it: write-through stores, loads that no CU's L1 serves
+// (tools/streams/xcd_coherence_probe.hip: sc1 stores + sc1 loads read fresh across XCDs also when the reader's L2 holds the
+// line's previous contents; plain loads do not).
+__device__ __forceinline__ void glds16o_dev(const float* base, const unsigned e, const unsigned lds_dst) {
+  unsigned keep;
+  const unsigned boff = e << 2;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 sc1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(boff), "s"(lds_dst), "s"(base) : "memory");
+}
+template <bool DEV>
+__device__ __forceinline__ void glds16o_t(const float* base, const unsigned e, const unsigned lds_dst) {
+  if (DEV) glds16o_dev(base, e, lds_dst); else glds16o(base, e, lds_dst);
+}
+template <bool DEV>
+__device__ __forceinline__ void sto4_t(float* base, const unsigned e, const float4& v) {
+  if (DEV) sto4_dev(base, e, v); else sto4(base, e, v);
+}
+__device__ __forceinline__ void cpml_row4_reg(float4& d, float4& ps, float b, float c, float ik);
+template <bool DEV>
+__device__ __forceinline__ void cpml_row4_t(float4& d, float* base, const unsigned o, float b, float c, float ik) {
+  if (!DEV) { cpml_row4(d, base, o, b, c, ik); return; }
+  float4 ps = ldb4_dev(dev_buf(base), o << 2, 0u);
+  cpml_row4_reg(d, ps, b, c, ik);
+  sto4_dev(base, o, ps);
+}
 __device__ __forceinline__ void cpml_row4_reg(float4& d, float4& ps, float b, float c, float ik) {
   ps.x = __builtin_fmaf(b, ps.x, c * d.x);
   ps.y = __builtin_fmaf(b, ps.y, c * d.y);
@@ -412,27 +476,29 @@ __device__ __forceinline__ int psi_off_y(const DevParams& p, const int k, const 
 }
 // Slots 2,3 take the z-directed pair in the z-layer planes (block-uniform: a block lies in one plane) and the y-directed
 // pair elsewhere; where both layers meet (edges, corners) the y pair is loaded directly, after the differences, as before.
+template <bool DEV = false>
 __device__ __forceinline__ void psi_stage_issue(const DevParams& p, float* const (&psi)[3][2], const unsigned stage, const bool valid,
                                                 const int k, const int j, const int i0) {
   if (!valid) return;
   const int ox = psi_off_x(p, k, j, i0);
   if (ox >= 0) {
-    glds16o(psi[1][1], (unsigned)ox, stage);
-    glds16o(psi[2][0], (unsigned)ox, stage + 1024u);
+    glds16o_t<DEV>(psi[1][1], (unsigned)ox, stage);
+    glds16o_t<DEV>(psi[2][0], (unsigned)ox, stage + 1024u);
   }
   const int oz = psi_off_z(p, k, j, i0);   // >= 0 for the whole block or for none of it (a block lies in one plane)
   if (oz >= 0) {
-    glds16o(psi[0][1], (unsigned)oz, stage + 2048u);
-    glds16o(psi[1][0], (unsigned)oz, stage + 3072u);
+    glds16o_t<DEV>(psi[0][1], (unsigned)oz, stage + 2048u);
+    glds16o_t<DEV>(psi[1][0], (unsigned)oz, stage + 3072u);
   } else {                                  // outside the z layers the same two slots take the y-directed pair
     const int oy = psi_off_y(p, k, j, i0);
     if (oy >= 0) {
-      glds16o(psi[0][0], (unsigned)oy, stage + 2048u);
-      glds16o(psi[2][1], (unsigned)oy, stage + 3072u);
+      glds16o_t<DEV>(psi[0][0], (unsigned)oy, stage + 2048u);
+      glds16o_t<DEV>(psi[2][1], (unsigned)oy, stage + 3072u);
     }
   }
 }
 // ... and use them: z pair on (dzA, dzB) = the two differences taken along z, x pair on (dxA, dxB) = along x.
+template <bool DEV = false>
 __device__ __forceinline__ void psi_stage_apply(const DevParams& p, float* const (&psi)[3][2], const int eh, const float4* s_psi, const float* s_xc,
                                                 const bool xc_lds, const int k, const int j, const int i0,
                                                 float4& dzA, float4& dzB, float4& dxA, float4& dxB, float4& dyA, float4& dyB) {
@@ -445,19 +511,19 @@ __device__ __forceinline__ void psi_stage_apply(const DevParams& p, float* const
       const float b = p.cp[2][eh][0][k], c = p.cp[2][eh][1][k], ik = p.cp[2][eh][2][k];
       float4 ps = mine[2 * 64];
       cpml_row4_reg(dzA, ps, b, c, ik);
-      sto4(psi[0][1], (unsigned)oz, ps);
+      sto4_t<DEV>(psi[0][1], (unsigned)oz, ps);
       __builtin_amdgcn_sched_barrier(0);
       ps = mine[3 * 64];
       cpml_row4_reg(dzB, ps, b, c, ik);
-      sto4(psi[1][0], (unsigned)oz, ps);
+      sto4_t<DEV>(psi[1][0], (unsigned)oz, ps);
     }
     __builtin_amdgcn_sched_barrier(0);
     const int oy = psi_off_y(p, k, j, i0);
     if (oy >= 0) {
       const float b = p.cp[1][eh][0][j], c = p.cp[1][eh][1][j], ik = p.cp[1][eh][2][j];
-      cpml_row4(dyA, psi[0][0], (unsigned)oy, b, c, ik);
+      cpml_row4_t<DEV>(dyA, psi[0][0], (unsigned)oy, b, c, ik);
       __builtin_amdgcn_sched_barrier(0);
-      cpml_row4(dyB, psi[2][1], (unsigned)oy, b, c, ik);
+      cpml_row4_t<DEV>(dyB, psi[2][1], (unsigned)oy, b, c, ik);
     }
   } else {         // elsewhere the stage holds the y pair
     const int oy = psi_off_y(p, k, j, i0);
@@ -465,11 +531,11 @@ __device__ __forceinline__ void psi_stage_apply(const DevParams& p, float* const
       const float b = p.cp[1][eh][0][j], c = p.cp[1][eh][1][j], ik = p.cp[1][eh][2][j];
       float4 ps = mine[2 * 64];
       cpml_row4_reg(dyA, ps, b, c, ik);
-      sto4(psi[0][0], (unsigned)oy, ps);
+      sto4_t<DEV>(psi[0][0], (unsigned)oy, ps);
       __builtin_amdgcn_sched_barrier(0);
       ps = mine[3 * 64];
       cpml_row4_reg(dyB, ps, b, c, ik);
-      sto4(psi[2][1], (unsigned)oy, ps);
+      sto4_t<DEV>(psi[2][1], (unsigned)oy, ps);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -485,11 +551,11 @@ __device__ __forceinline__ void psi_stage_apply(const DevParams& p, float* const
     }
     float4 ps = mine[0];
     cpml_x4_apply(dxA, ps, b, c, ik);
-    sto4(psi[1][1], (unsigned)ox, ps);
+    sto4_t<DEV>(psi[1][1], (unsigned)ox, ps);
     __builtin_amdgcn_sched_barrier(0);
     ps = mine[64];
     cpml_x4_apply(dxB, ps, b, c, ik);
-    sto4(psi[2][0], (unsigned)ox, ps);
+    sto4_t<DEV>(psi[2][0], (unsigned)ox, ps);
   }
   __builtin_amdgcn_sched_barrier(0);
 }

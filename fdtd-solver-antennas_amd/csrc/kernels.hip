@@ -94,10 +94,13 @@ __device__ __forceinline__ void mur_post_inline(const DevParams& p, const MurDev
 // WF: the block is part of a one-launch-per-timestep wavefront (k_step below): V goes out write-through (sc1) and the block
 // publishes its flag when every wave's stores have been acknowledged.
 // MUR: the block also runs the Mur "post" pass (S += coeff * V_new on the plane next to each Mur face) for the points it owns.
-template <int COEF, bool PML, bool FUSE, bool P2P, bool WF, bool MUR = false>
+// MULTI: the block is part of a launch of SEVERAL timesteps (k_step): what it reads was written — and what it overwrites was
+// read — by workgroups of the previous timestep of the same launch, so it first waits for their flags (back_target != 0) and
+// every load of mutable data is a device-scope load, every store a write-through store (fields and psi alike).
+template <int COEF, bool PML, bool FUSE, bool P2P, bool WF, bool MUR = false, bool MULTI = false>
 __device__ __forceinline__ void body_E(const DevParams& p, const int strip, const int k, const int pb, const long long step,
                                        float2* const s_lut, float4* const s_psi, float* const s_xc, SrcStage& s_src, const unsigned wf_target,
-                                       const MurDev* const mur = nullptr) {
+                                       const MurDev* const mur = nullptr, const unsigned back_target = 0u) {
   // coefficient table -> LDS by LDS-DMA, issued FIRST: no staging registers (the kernel has none to spare), and since
   // vector-memory operations retire in order a counted wait below leaves the field loads behind it in flight.
   // Thread t moves entries 2t, 2t+1 (16 bytes; the destination of an LDS-DMA load is lane-linear, so the table lands
@@ -123,15 +126,35 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
   // pointers (SGPRs are plentiful, VGPRs decide the occupancy); bases start one plane below plane 0 (the ghost plane), so
   // that the offset stays unsigned whatever the displacement
   const unsigned uo = (unsigned)(off + p.plane);
-  const float *I0 = p.I[0] - p.plane, *I1 = p.I[1] - p.plane, *I2 = p.I[2] - p.plane;
-  const float4 ix = ldo4(I0, uo), iy = ldo4(I1, uo), iz = ldo4(I2, uo);
-  const float4 iz_jm = ldo4(I2 - p.P, uo), ix_jm = ldo4(I0 - p.P, uo);
   // P2P: the k-1 neighbours of the bottom plane are the lower rank's top plane and come from the mailbox (below)
   const bool dep_in = P2P && k == 0 && p.mb_in_H != nullptr;
+  float4 ix, iy, iz, iz_jm, ix_jm, vx, vy, vz;
   float4 iy_km = make_float4(0.f, 0.f, 0.f, 0.f), ix_km = iy_km;
-  if (!dep_in) { iy_km = ldo4(I1 - p.plane, uo); ix_km = ldo4(I0 - p.plane, uo); }
-  const float iz_im = ldo1(I2 - 1, uo), iy_im = ldo1(I1 - 1, uo);
-  float4 vx = ldo4(p.V[0] - p.plane, uo), vy = ldo4(p.V[1] - p.plane, uo), vz = ldo4(p.V[2] - p.plane, uo);
+  float iz_im, iy_im;
+  if (!MULTI) {
+    const float *I0 = p.I[0] - p.plane, *I1 = p.I[1] - p.plane, *I2 = p.I[2] - p.plane;
+    ix = ldo4(I0, uo); iy = ldo4(I1, uo); iz = ldo4(I2, uo);
+    iz_jm = ldo4(I2 - p.P, uo); ix_jm = ldo4(I0 - p.P, uo);
+    if (!dep_in) { iy_km = ldo4(I1 - p.plane, uo); ix_km = ldo4(I0 - p.plane, uo); }
+    iz_im = ldo1(I2 - 1, uo); iy_im = ldo1(I1 - 1, uo);
+    vx = ldo4(p.V[0] - p.plane, uo); vy = ldo4(p.V[1] - p.plane, uo); vz = ldo4(p.V[2] - p.plane, uo);
+  } else {
+    // the H blocks of the previous timestep that wrote what this block reads have published (and the probe blocks that sample
+    // V cells of this strip-plane have read them); then device-scope loads: one buffer resource per array, based one plane
+    // below plane 0, the neighbour displacements in the scalar offset
+    if (back_target) {
+      wf_wait_back(p, k, strip, pb, back_target);
+      if (p.wf_prbV_sp != nullptr && sload_int(p.wf_prbV_sp + (k * p.nstrips + strip)) != 0) wf_wait_probes(p, FDTD_KIND_V, back_target);
+    }
+    const DevRsrc r0 = dev_buf(p.I[0] - 2 * p.plane), r1 = dev_buf(p.I[1] - 2 * p.plane), r2 = dev_buf(p.I[2] - 2 * p.plane);
+    const unsigned bo = (unsigned)off << 2, d0 = (unsigned)(2 * p.plane) << 2, dj = (unsigned)(2 * p.plane - p.P) << 2,
+                   dk = (unsigned)p.plane << 2, di = (unsigned)(2 * p.plane - 1) << 2;
+    ix = ldb4_dev(r0, bo, d0); iy = ldb4_dev(r1, bo, d0); iz = ldb4_dev(r2, bo, d0);
+    iz_jm = ldb4_dev(r2, bo, dj); ix_jm = ldb4_dev(r0, bo, dj);
+    iy_km = ldb4_dev(r1, bo, dk); ix_km = ldb4_dev(r0, bo, dk);
+    iz_im = ldb1_dev(r2, bo, di); iy_im = ldb1_dev(r1, bo, di);
+    vx = ldb4_dev(dev_buf(p.V[0]), bo, 0u); vy = ldb4_dev(dev_buf(p.V[1]), bo, 0u); vz = ldb4_dev(dev_buf(p.V[2]), bo, 0u);
+  }
   MurVals mv;
   if (MUR && valid) mur_post_inline<0>(p, *mur, k, j, i0, mv, vx, vy, vz);   // the S values of the Mur post pass travel with the field loads
   // Soft sources inside this strip-plane (block-uniform range; almost always empty).  The range comes by an explicit SCALAR
@@ -144,7 +167,7 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
     if (srng.y > srng.x) stage_sources(p, p.src_ids, srng.x, min(srng.y - srng.x, FDTD_BLOCK), step, s_src);
   }
   if (PML && FDTD_PSI_STAGE)   // psi of the x / z layers: LDS-DMA right behind the field loads (kernel_common.hpp)
-    psi_stage_issue(p, p.psiE, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
+    psi_stage_issue<MULTI>(p, p.psiE, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
   if (dep_in) {   // H halo of step-1 (tag = step + 1; for step 0 the neighbour's INITIAL top plane, pushed by k_p2p_prime); slot of the parity of the step that produced it
     const float* mb = p.mb_in_H + (size_t)((step + 1) & 1) * 2 * mb_slot_words(p);
     mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u, ix_km, iy_km, p.p2p_err, p.p2p_limit);
@@ -171,7 +194,7 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
 
   if (PML) {
     if (FDTD_PSI_STAGE) {
-      psi_stage_apply(p, p.psiE, 0, s_psi, s_xc, xc_lds, k, j, i0, dx2, dy1, dy2, dz1, dx1, dz2);
+      psi_stage_apply<MULTI>(p, p.psiE, 0, s_psi, s_xc, xc_lds, k, j, i0, dx2, dy1, dy2, dz1, dx1, dz2);
     } else {
       const int sy = pml_slot(p, 1, j);
       if (sy >= 0) {
@@ -311,9 +334,10 @@ __device__ __forceinline__ void mur_pre_block(const DevParams& p, const unsigned
 // ------------------------------------------------------------------------------------------------
 // K2: H half-step
 // ------------------------------------------------------------------------------------------------
-template <bool RAW, bool PML, bool P2P, bool WF>
+template <bool RAW, bool PML, bool P2P, bool WF, bool MULTI = false>
 __device__ __forceinline__ void body_H(const DevParams& p, const int strip, const int k, const int pb, const long long step,
-                                       float4* const s_psi, float* const s_xc, const unsigned wf_target) {
+                                       float4* const s_psi, float* const s_xc, const unsigned wf_target, const unsigned back_target = 0u) {
+  static_assert(!(MULTI && P2P), "several timesteps per launch: single slabs only");
   int j = 0, i0 = 0;
   const bool staged = PML && FDTD_PSI_STAGE;
   const bool xc_lds = staged && p.xc_tab != nullptr;
@@ -342,10 +366,22 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
     // wavefront block: everything that does not depend on this launch's E blocks first (I, psi), then the flags of the E
     // blocks this block reads from, then V with device-scope (sc1) loads — they bypass this CU's L1, which no other CU's
     // store ever refreshes, and are served by L2 / the Infinity Cache, where the write-through stores of body_E land
-    ix = ldo4(p.I[0], uo); iy = ldo4(p.I[1], uo); iz = ldo4(p.I[2], uo);
-    if (staged)
-      psi_stage_issue(p, p.psiH, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
+    if (!MULTI) {
+      ix = ldo4(p.I[0], uo); iy = ldo4(p.I[1], uo); iz = ldo4(p.I[2], uo);
+      if (staged)
+        psi_stage_issue(p, p.psiH, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
+    }
     wf_wait(p, k, strip, pb, wf_target + p.wf_wait_bias);
+    if (MULTI) {
+      // Several timesteps per launch: this block's I and psi were written by another workgroup of the SAME launch — the H block
+      // of these cells one timestep ago.  That it has finished is only known HERE: the E block of these cells waited for its
+      // flag, and this block has just seen the E block's.  Device-scope loads; and the probe blocks of the previous timestep
+      // have read the I cells of this strip-plane before it overwrites them.
+      if (back_target && p.wf_prb_sp != nullptr && sload_int(p.wf_prb_sp + (k * p.nstrips + strip)) != 0) wf_wait_probes(p, FDTD_KIND_I, back_target);
+      ix = ldb4_dev(dev_buf(p.I[0]), uo << 2, 0u); iy = ldb4_dev(dev_buf(p.I[1]), uo << 2, 0u); iz = ldb4_dev(dev_buf(p.I[2]), uo << 2, 0u);
+      if (staged)
+        psi_stage_issue<true>(p, p.psiH, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
+    }
     const DevRsrc b0 = dev_buf(p.V[0]), b1 = dev_buf(p.V[1]), b2 = dev_buf(p.V[2]);
     const unsigned bo = uo << 2;
     vx = ldb4_dev(b0, bo, 0u); vy = ldb4_dev(b1, bo, 0u); vz = ldb4_dev(b2, bo, 0u);
@@ -371,12 +407,13 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
   }
   // wavefront block of a strip-plane that holds I-probe cells: its I goes out write-through and it publishes a flag of its
   // own, for the probe blocks at the end of the launch (wf_probe_tail); such a block meets once more, so nobody leaves early
-  const bool pub = WF && p.wf_prb_sp != nullptr && sload_int(p.wf_prb_sp + (k * p.nstrips + strip)) != 0;
+  // (several timesteps per launch: EVERY H block does — the E blocks of the next timestep wait for these flags)
+  const bool pub = MULTI || (WF && p.wf_prb_sp != nullptr && sload_int(p.wf_prb_sp + (k * p.nstrips + strip)) != 0);
   if (!WF || valid) {
 
   if (PML) {
     if (FDTD_PSI_STAGE) {
-      psi_stage_apply(p, p.psiH, 1, s_psi, s_xc, xc_lds, k, j, i0, dx2, dy1, dy2, dz1, dx1, dz2);
+      psi_stage_apply<MULTI>(p, p.psiH, 1, s_psi, s_xc, xc_lds, k, j, i0, dx2, dy1, dy2, dz1, dx1, dz2);
     } else {
       const int sy = pml_slot(p, 1, j);
       if (sy >= 0) {
@@ -472,18 +509,34 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
 #define FDTD_XCD_TRACE_MAX 65536
 __device__ unsigned long long g_xcd_trace[2 * FDTD_XCD_TRACE_MAX * 4];   // [step & 1][block][start, end, XCC_ID | E/H << 3 | valid << 4, step]
 #endif
-template <int COEF, bool PML, bool P2P>
-__global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_MINBLOCKS) void k_step(const DevParams p, const long long step, const int lag, const unsigned wf_target,
-                                                                        const unsigned nbp, const FastDiv fd_2m, const int down, const unsigned nmain) {
+// MULTI: `fd_per.d` blocks per timestep (the main blocks, then the probe blocks, padded to a multiple of eight so that a share
+// keeps its XCD from timestep to timestep), timestep after timestep in ONE launch: no kernel boundary, the E blocks of
+// timestep s + 1 start while the H blocks of timestep s drain.  Only the order "all E blocks, then all H blocks" (lag < 0),
+// every timestep in the same direction (an E block waits for the H block of its cells one timestep earlier: half a timestep's
+// blocks back in dispatch order, long finished — walking backwards it would be the block dispatched last).
+template <int COEF, bool PML, bool P2P, bool MULTI = false>
+__global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_MINBLOCKS) void k_step(const DevParams p, const long long step0, const int lag, const unsigned wf_target0,
+                                                                        const unsigned nbp, const FastDiv fd_2m, const int down, const unsigned nmain,
+                                                                        const FastDiv fd_per) {
   extern __shared__ float2 s_lut[];
   __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : FDTD_BLOCK / 2];   // (the probe blocks borrow it for their reduction)
   __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
   __shared__ SrcStage s_src;
-  const unsigned b = blockIdx.x, x = b & 7u, pos = b >> 3;
-  if (b >= nmain) {   // the last blocks of the launch: one per probe
-    wf_probe_tail(p, (int)(b - nmain), step, wf_target, reinterpret_cast<double*>(s_psi));
+  unsigned b = blockIdx.x;
+  long long step = step0;
+  unsigned wf_target = wf_target0, ts = 0u;
+  if (MULTI) {   // which timestep of the launch
+    ts = fd_div(b, fd_per);
+    b -= ts * fd_per.d;
+    step += ts;
+    wf_target += ts;
+  }
+  const unsigned x = b & 7u, pos = b >> 3;
+  if (b >= nmain) {   // the last blocks of the timestep: one per probe
+    if ((int)(b - nmain) < p.nprobe) wf_probe_tail<MULTI>(p, (int)(b - nmain), step, wf_target, reinterpret_cast<double*>(s_psi));
     return;
   }
+  if (p.xstamp && b < 8u && threadIdx.x == 0) p.xstamp[p.xstamp_n + b] = wall_clock64();   // calibration launch: when the shares started
   bool is_h;
   int k, pb;
   unsigned strip;
@@ -522,8 +575,9 @@ __global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_M
   // 32-byte slot of a per-launch table (two tables, alternating with the step): plain stores, no atomics, no extra barrier
   const unsigned long long t_begin = wall_clock64();
 #endif
-  if (!is_h) body_E<COEF, PML, true, P2P, true>(p, (int)strip, k, pb, step, s_lut, s_psi, s_xc, s_src, wf_target);
-  else body_H<COEF == 0, PML, P2P, true>(p, (int)strip, k, pb, step, s_psi, s_xc, wf_target);
+  if (!is_h) body_E<COEF, PML, true, P2P, true, false, MULTI>(p, (int)strip, k, pb, step, s_lut, s_psi, s_xc, s_src, wf_target, nullptr, ts ? wf_target - 1u : 0u);
+  else body_H<COEF == 0, PML, P2P, true, MULTI>(p, (int)strip, k, pb, step, s_psi, s_xc, wf_target, ts ? wf_target - 1u : 0u);
+  if (p.xstamp && threadIdx.x == 0) p.xstamp[b] = wall_clock64();   // ... and when this block (its first wave) was done
 #ifdef FDTD_XCD_TRACE
   if (threadIdx.x == 0 && b < FDTD_XCD_TRACE_MAX) {
     unsigned xid;
@@ -810,15 +864,16 @@ static void strip_block_costs(const fdtd_ctx* c, std::vector<double>& act, std::
     }
   }
 }
-static void cut_shares(const std::vector<double>& cost, unsigned (&xs)[9], unsigned& grid) {
+static void cut_shares(const std::vector<double>& cost, const double (&frac)[8], unsigned (&xs)[9], unsigned& grid) {
   const size_t n = cost.size();
   double total = 0.0;
   for (double v : cost) total += v;
-  double run = 0.0;
+  double run = 0.0, upto = 0.0;
   size_t v = 0;
   xs[0] = 0u;
   for (int x = 1; x < 8; ++x) {
-    const double target = total * x / 8.0;
+    upto += frac[x - 1];
+    const double target = total * upto;
     // the block that straddles the target goes to whichever side leaves the smaller error
     while (v < n && run + cost[v] <= target) run += cost[v++];
     if (v < n && target - run > run + cost[v] - target) run += cost[v++];
@@ -843,7 +898,8 @@ static void set_xcd_shares(fdtd_ctx* c, int k_first, int planes) {
   if (it == c->xcd_cache.end()) {
     fdtd_ctx::XcdShare sh{};
     const unsigned n = (unsigned)p.nstrips * (unsigned)planes * (unsigned)p.nbs;
-    if (!c->xcd_balance || !c->have_cpml) equal_shares(n, sh.xs, sh.grid);
+    const bool full = k_first == 0 && planes == p.nk && c->xcd_adapt_done > 0;   // measured fractions: the whole-slab launches of k_step
+    if (!c->xcd_balance || (!c->have_cpml && !full)) equal_shares(n, sh.xs, sh.grid);
     else {
       std::vector<double> act, ylay, cost((size_t)n);
       strip_block_costs(c, act, ylay);
@@ -857,7 +913,8 @@ static void set_xcd_shares(fdtd_ctx* c, int k_first, int planes) {
                 XCD_BLOCK_CONST * FDTD_BLOCK + a + c->xw_y * y + (zl ? c->xw_z * a + c->xw_yz * y : 0.0);
           }
         }
-      cut_shares(cost, sh.xs, sh.grid);
+      static const double eighth[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
+      cut_shares(cost, full ? c->xfrac : eighth, sh.xs, sh.grid);
     }
     it = c->xcd_cache.emplace(key, sh).first;
   }
@@ -874,9 +931,72 @@ static void set_plane_shares(fdtd_ctx* c) {
     std::vector<double> act, ylay, cost((size_t)nbp);
     strip_block_costs(c, act, ylay);
     for (size_t q = 0; q < cost.size(); ++q) cost[q] = XCD_BLOCK_CONST * FDTD_BLOCK + act[q] + c->xw_y * ylay[q];
-    cut_shares(cost, p.ps, grid);
+    cut_shares(cost, c->pfrac, p.ps, grid);
   }
   p.pm = grid / 8u;
+}
+
+// ---- measured XCD shares -------------------------------------------------------------------------------------------------
+// The cost model above knows the bytes a block moves, not the chip it runs on: traced per XCD (tools/xcd_trace.py), the eight
+// shares of a north-star launch finish up to 5 us apart, in a pattern that differs from box to box and has nothing to do with
+// the CPML layers.  So the last k_step launch of an fdtd_run call leaves every block's end time (one 8-byte store per block,
+// no atomics), and when the call has drained anyway the host takes each share's finish time T_x (its last block, measured
+// from the launch's first block) and moves its cost fraction towards what would have made it finish with the others:
+//   f_x <- f_x * (mean(T) / T_x)^g, renormalised, clamped to [1/16, 1/4];  g = 0.75 for the first two corrections, 0.4 after
+// (one launch is a noisy sample: +-1.5 % per share on the north-star grid, +-5 % on 200x200x40).
+// Measured (profiles/r03/xcd_adaptive_shares_ab.txt): first sample of a north-star context 0.92 .. 1.06 of the mean, after
+// three corrections 0.99 .. 1.01; NS 72.2 -> 70.7 us per timestep, 200x200x40 27.5 -> 26.7.  Only for the order "all E
+// blocks, then all H blocks": in plane groups the XCD groups advance in step (flags) and finish within the noise anyway.
+// Results do not depend on the shares (a block computes the same cells wherever it runs); only the time does.
+int xcd_stamp_arm(fdtd_ctx* c, hipStream_t s) {
+  if (!c->xcd_adapt || !c->xcd_balance || c->p.p2p || wf_lag_for(c) < c->p.nk) return FDTD_OK;
+  // room for the largest launch this slab can make (either order of k_step) + the eight start stamps
+  const size_t nbp = (size_t)c->p.nstrips * c->p.nbs;
+  const size_t need = 2 * (nbp + 8) * (size_t)(c->p.nk + 64) + 64;   // (plane groups: 16 * m * (nk + lag), m <= nbp / 8 + 1, lag small)
+  if (need > ((size_t)1 << 24)) return FDTD_OK;                       // 128 MiB of stamps: not worth it
+  if (c->xstamp_cap < need) {
+    hipFree(c->xstamp); c->xstamp = nullptr; c->xstamp_cap = 0;
+    if (hipMalloc(&c->xstamp, need * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); return FDTD_OK; }
+    c->xstamp_cap = need;
+  }
+  HIPCK(c, hipMemsetAsync(c->xstamp, 0, c->xstamp_cap * sizeof(unsigned long long), s));
+  c->p.xstamp = c->xstamp;
+  c->xstamp_grid = 0; c->xstamp_mode = 0;
+  return FDTD_OK;
+}
+
+int xcd_adapt(fdtd_ctx* c) {
+  if (!c->xstamp || !c->xstamp_grid || !c->xstamp_mode) return FDTD_OK;
+  const unsigned n = c->xstamp_grid;
+  std::vector<unsigned long long> h((size_t)n + 8);
+  HIPCK(c, hipMemcpy(h.data(), c->xstamp, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  const int mode = c->xstamp_mode;
+  c->xstamp_grid = 0; c->xstamp_mode = 0;
+  unsigned long long t0 = ~0ull, last[8] = {};
+  for (unsigned x = 0; x < 8; ++x) if (h[n + x]) t0 = std::min(t0, h[n + x]);
+  for (unsigned b = 0; b < n; ++b) last[b & 7u] = std::max(last[b & 7u], h[b]);
+  double T[8], mean = 0.0;
+  for (int x = 0; x < 8; ++x) {
+    if (!last[x] || t0 == ~0ull || last[x] <= t0) return FDTD_OK;    // a share without blocks, or no stamps: leave everything as it is
+    T[x] = (double)(last[x] - t0);
+    mean += T[x] / 8.0;
+  }
+  if (mode != 1) return FDTD_OK;
+  double (&f)[8] = c->xfrac;
+  const double gain = c->xcd_adapt_done < 2 ? 0.75 : 0.4;
+  double sum = 0.0;
+  for (int x = 0; x < 8; ++x) { f[x] = std::min(0.25, std::max(0.0625, f[x] * std::pow(mean / T[x], gain))); sum += f[x]; }
+  for (int x = 0; x < 8; ++x) f[x] /= sum;
+  c->xcd_adapt_done++;
+  xcd_shares_reset(c);
+  if (getenv("FDTD_XCD_DEBUG")) {
+    fprintf(stderr, "[fdtd-hip] xcd_adapt #%d (%s): finish times / mean", c->xcd_adapt_done, mode == 1 ? "E then H" : "plane groups");
+    for (int x = 0; x < 8; ++x) fprintf(stderr, " %.3f", T[x] / mean);
+    fprintf(stderr, " -> fractions");
+    for (int x = 0; x < 8; ++x) fprintf(stderr, " %.4f", f[x]);
+    fprintf(stderr, "\n");
+  }
+  return FDTD_OK;
 }
 
 // Occupancy cap without recompiling (experiments): dynamic LDS padding so that at most `cap` blocks fit the CU's
@@ -985,7 +1105,7 @@ int wf_lag_for(const fdtd_ctx* c) {
 }
 
 template <int COEF, bool PML, bool P2P>
-static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s) {
+static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s, int nsteps) {
   const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs;
   const unsigned lut_bytes = (unsigned)(c->raw_op ? 0 : (c->p.lut_n + 1) / 2) * 16u;
   const unsigned pad = lut_bytes + lds_pad(c->occ_wf, (PML && FDTD_PSI_STAGE ? 20480u : 2560u) + lut_bytes);
@@ -993,27 +1113,41 @@ static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s) {
   if (lag >= c->p.nk) {   // all E blocks, then all H blocks (cache-resident slabs: wf_lag_for), each half in eight cost-weighted XCD shares
     set_xcd_shares(c, 0, c->p.nk);
     const unsigned nE = c->p.xgrid;
+    if (c->p.xstamp) {
+      if ((size_t)2u * nE + 8u > c->xstamp_cap) c->p.xstamp = nullptr;   // (the table was sized for other shares: skip this calibration)
+      else { c->p.xstamp_n = 2u * nE; c->xstamp_grid = 2u * nE; c->xstamp_mode = 1; }
+    }
+    if (nsteps > 1) {   // several timesteps in one launch (never a P2P slab: launch_step_wf); every timestep walks forwards
+      const unsigned per = 2u * nE + (((unsigned)c->nprobe + 7u) & ~7u);
+      c->p.xstamp = nullptr;
+      if constexpr (!P2P)
+        launch_main(c, k_step<COEF, PML, false, true>, dim3(per * (unsigned)nsteps), pad, s, c->p, step, -1, c->wf_epoch - (unsigned)(nsteps - 1), nbp,
+                    make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), 0, 2u * nE, make_fastdiv(per));
+      return;
+    }
     launch_main(c, k_step<COEF, PML, P2P>, dim3(2u * nE + (unsigned)c->nprobe), pad, s, c->p, step, -1, c->wf_epoch, nbp,
-                make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), down, 2u * nE);
+                make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), down, 2u * nE, make_fastdiv(1u));
+    c->p.xstamp = nullptr;
     return;
   }
   set_plane_shares(c);
   const unsigned m = c->p.pm;   // positions per role in a plane group: the largest XCD share of a plane
   const unsigned nmain = 8u * 2u * m * (unsigned)(c->p.nk + lag);
   const dim3 grid(nmain + (unsigned)c->nprobe);
-  launch_main(c, k_step<COEF, PML, P2P>, grid, pad, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m), down, nmain);
+  c->p.xstamp = nullptr;   // (no calibration in this order: the XCD groups advance in step)
+  launch_main(c, k_step<COEF, PML, P2P>, grid, pad, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m), down, nmain, make_fastdiv(1u));
 }
 template <int COEF, bool PML>
-static void launch_step2(fdtd_ctx* c, long long step, int lag, hipStream_t s) {
-  if (c->p.p2p) launch_step3<COEF, PML, true>(c, step, lag, s);
-  else launch_step3<COEF, PML, false>(c, step, lag, s);
+static void launch_step2(fdtd_ctx* c, long long step, int lag, hipStream_t s, int nsteps) {
+  if (c->p.p2p) launch_step3<COEF, PML, true>(c, step, lag, s, 1);
+  else launch_step3<COEF, PML, false>(c, step, lag, s, nsteps);
 }
 
 // Probe tables of the wavefront launch: which blocks own each probe's cells (the probe block waits for their flags), and which
 // strip-planes hold I-probe cells (their H blocks store write-through and publish).  Rebuilt when a probe was added.
 static int build_wf_probe_tables(fdtd_ctx* c, hipStream_t s) {
   const int nsp = c->p.nk * c->p.nstrips;
-  std::vector<int> sp(nsp, 0), blk;
+  std::vector<int> sp(nsp, 0), spV(nsp, 0), blk;
   std::vector<int2> rng(FDTD_MAX_PROBES, make_int2(0, 0));
   for (int q = 0; q < c->nprobe; ++q) {
     std::vector<int> mine;
@@ -1021,7 +1155,7 @@ static int build_wf_probe_tables(fdtd_ctx* c, hipStream_t s) {
       const int k = off / c->plane, r = off - k * c->plane, j = r / c->P, i = r - j * c->P;
       const int strip = j / c->p.tys, t = (j - strip * c->p.tys) * c->p.P4 + i / 4;
       mine.push_back((k * c->p.nstrips + strip) * c->p.nbs + t / FDTD_BLOCK);
-      if (c->probe[q].kind == FDTD_KIND_I) sp[k * c->p.nstrips + strip] = 1;
+      (c->probe[q].kind == FDTD_KIND_I ? sp : spV)[k * c->p.nstrips + strip] = 1;
     }
     std::sort(mine.begin(), mine.end());
     mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
@@ -1030,8 +1164,14 @@ static int build_wf_probe_tables(fdtd_ctx* c, hipStream_t s) {
   }
   if (blk.empty()) blk.push_back(0);
   HIPCK(c, hipStreamSynchronize(s));     // nothing in flight reads the old tables
-  hipFree(c->wf_prb_sp); hipFree(c->wf_prb_blk); hipFree(c->wf_prb_rng);
-  c->wf_prb_sp = nullptr; c->wf_prb_blk = nullptr; c->wf_prb_rng = nullptr;
+  hipFree(c->wf_prb_sp); hipFree(c->wf_prb_blk); hipFree(c->wf_prb_rng); hipFree(c->wf_prbV_sp);
+  c->wf_prb_sp = nullptr; c->wf_prb_blk = nullptr; c->wf_prb_rng = nullptr; c->wf_prbV_sp = nullptr;
+  HIPCK(c, hipMalloc(&c->wf_prbV_sp, spV.size() * sizeof(int)));
+  HIPCK(c, hipMemcpy(c->wf_prbV_sp, spV.data(), spV.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (!c->wf_prb_done) {
+    HIPCK(c, hipMalloc(&c->wf_prb_done, FDTD_MAX_PROBES * sizeof(unsigned)));
+    HIPCK(c, hipMemset(c->wf_prb_done, 0, FDTD_MAX_PROBES * sizeof(unsigned)));
+  }
   HIPCK(c, hipMalloc(&c->wf_prb_sp, sp.size() * sizeof(int)));
   HIPCK(c, hipMalloc(&c->wf_prb_blk, blk.size() * sizeof(int)));
   HIPCK(c, hipMalloc(&c->wf_prb_rng, rng.size() * sizeof(int2)));
@@ -1042,7 +1182,16 @@ static int build_wf_probe_tables(fdtd_ctx* c, hipStream_t s) {
   return FDTD_OK;
 }
 
-int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s) {
+// Timesteps one launch may hold: the order "all E blocks, then all H blocks" on a single slab (wf_lag_for == nk), the grid
+// within 2^31 blocks; $FDTD_WF_MULTI caps it (1: one launch per timestep, as in round 2).
+int wf_multi_max(const fdtd_ctx* c) {
+  if (c->p.p2p || c->d.world != 1 || c->wf_multi <= 1 || wf_lag_for(c) < c->p.nk) return 1;
+  const unsigned long long per = 2ull * ((unsigned long long)c->p.nstrips * c->p.nk * c->p.nbs + 64ull) + 64ull;
+  const unsigned long long fit = ((1ull << 31) - 1ull) / per;
+  return (int)std::max(1ull, std::min<unsigned long long>((unsigned long long)c->wf_multi, fit));
+}
+
+int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s, int nsteps) {
   const size_t nflags = (size_t)c->p.nk * c->p.nstrips * c->p.nbs;
   if (!c->wf_flags || c->wf_nflags != nflags) {   // first use (or a new tiling): flags start at 0, the epoch counts the launches
     if (c->wf_flags) hipFree(c->wf_flags);
@@ -1060,21 +1209,23 @@ int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s) {
   if (c->wf_prb_dirty) { int r = build_wf_probe_tables(c, s); if (r) return r; }
   c->p.wf_flags = c->wf_flags; c->p.wf_err = c->wf_err;
   c->p.wf_flagsH = c->wf_flagsH; c->p.wf_prb_sp = c->wf_prb_sp; c->p.wf_prb_blk = c->wf_prb_blk; c->p.wf_prb_rng = c->wf_prb_rng;
+  c->p.wf_prbV_sp = c->wf_prbV_sp; c->p.wf_prb_done = c->wf_prb_done;
   c->p.wf_limit = 200000000ull;   // 2 s of the 100 MHz wall clock
   c->p.wf_wait_bias = 0u;
-  if (step == c->wf_fault_step) { c->p.wf_wait_bias = 1u; c->p.wf_limit = 2000ull; }   // test hook: a flag value nobody publishes, 20 us
+  if (c->wf_fault_step >= step && c->wf_fault_step < step + nsteps) { c->p.wf_wait_bias = 1u; c->p.wf_limit = 2000ull; }   // test hook: a flag value nobody publishes, 20 us
   if (2 * (1 + c->p.P4 / FDTD_BLOCK) + 3 > 64) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "wavefront schedule: rows of more than %d cells", 30 * FDTD_BLOCK * 4);
-  ++c->wf_epoch;
+  if (nsteps > 1 && nsteps > wf_multi_max(c)) return fdtd_fail(c, FDTD_E_ARG, "%d timesteps in one launch: at most %d here", nsteps, wf_multi_max(c));
+  c->wf_epoch += (unsigned)nsteps;      // the flag value of the launch's LAST timestep
   const int lag = wf_lag_for(c);
   const int coef = c->raw_op ? 0 : (c->packed_op ? 2 : 1);
   if (c->have_cpml) {
-    if (coef == 0) launch_step2<0, true>(c, step, lag, s);
-    else if (coef == 1) launch_step2<1, true>(c, step, lag, s);
-    else launch_step2<2, true>(c, step, lag, s);
+    if (coef == 0) launch_step2<0, true>(c, step, lag, s, nsteps);
+    else if (coef == 1) launch_step2<1, true>(c, step, lag, s, nsteps);
+    else launch_step2<2, true>(c, step, lag, s, nsteps);
   } else {
-    if (coef == 0) launch_step2<0, false>(c, step, lag, s);
-    else if (coef == 1) launch_step2<1, false>(c, step, lag, s);
-    else launch_step2<2, false>(c, step, lag, s);
+    if (coef == 0) launch_step2<0, false>(c, step, lag, s, nsteps);
+    else if (coef == 1) launch_step2<1, false>(c, step, lag, s, nsteps);
+    else launch_step2<2, false>(c, step, lag, s, nsteps);
   }
   return FDTD_OK;
 }

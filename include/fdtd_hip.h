@@ -82,8 +82,11 @@ enum {
   FDTD_FLAG_KERNEL_WAVEFRONT = 5, /* ONE launch per timestep: the E sweep runs a few planes ahead of the H sweep, coupled by per-block
                                     flags, so that H reads what E just touched from the Infinity Cache instead of HBM.  Single slab, or
                                     slabs on the p2p mailbox transport; no Mur faces (else FDTD_E_UNSUPPORTED).  Below 256 MiB of fields all E blocks
-                                    run first, then all H blocks.  DIRECT never takes it.  Results are identical to the
-                                    two-pass kernels bit for bit.  fdtd_profile.fused = 1: ms_update_e is the whole timestep's launch. */
+                                    run first, then all H blocks — and on a single slab ONE launch then holds SEVERAL timesteps (up to 64,
+                                    cut at the timesteps whose NF2FF faces are sampled; fdtd_schedule_info info[7]): no kernel boundary, the E
+                                    blocks of the next timestep start while the H blocks of this one drain.  DIRECT never takes it.
+                                    Results are identical to the two-pass kernels bit for bit.  fdtd_profile.fused = 1: ms_update_e is the
+                                    main-launch time per timestep. */
   FDTD_FLAG_KERNEL_MASK   = 0xF,
   FDTD_FLAG_OVERLAP_ON    = 0x20, /* multi-slab: split sweeps into interior + halo-dependent plane (the default) */
   FDTD_FLAG_OVERLAP_OFF   = 0x40, /* multi-slab: one launch per sweep, after the halo has arrived */
@@ -112,7 +115,8 @@ typedef struct fdtd_desc {
 
 typedef struct fdtd_profile {
   double ms_total;        /* stream time for the profiled steps, HIP events */
-  double ms_update_e;     /* average begin-to-end duration of one E half-step main kernel launch */
+  double ms_update_e;     /* average begin-to-end duration of one E half-step main kernel launch; fused = 1: of the main launches PER
+                             TIMESTEP (their durations summed, over `steps`: a launch may hold several timesteps, launches_e tells) */
   double ms_update_h;     /* average begin-to-end duration of one H half-step main kernel launch */
   int32_t launches_e;     /* launches averaged */
   int32_t launches_h;
@@ -224,7 +228,11 @@ int fdtd_get_step(fdtd_ctx* ctx, int64_t* step);
  *   info[1] one launch per timestep only: planes the E sweep runs ahead of the H sweep (== nk: all E blocks, then all H blocks)
  *   info[2] rows per strip, info[3] blocks (of 1024 cells) per sweep
  *   info[4] halo transport: 0 none (single slab), 1 p2p mailbox, 2 RCCL, 3 linked contexts, 4 external (fdtd_half_step)
- *   info[5] 1 if the XCD shares are cost-weighted (CPML layers present), info[6..7] reserved (0) */
+ *   info[5] 1 if the XCD shares are cost-weighted (CPML layers present)
+ *   info[6] how often the shares have been re-cut from MEASURED per-XCD finish times so far (the last launch of an
+ *           fdtd_run call of >= 16 timesteps on a single slab is a calibration launch: every block leaves its end time)
+ *   info[7] one launch per timestep only: how many timesteps ONE launch may hold (cache-resident single slabs: up to 64, cut
+ *           at the timesteps whose NF2FF faces are sampled; 1: a launch per timestep) */
 int fdtd_schedule_info(fdtd_ctx* ctx, int32_t info[8]);
 /* sums[0] = sum V^2, sums[1] = sum I^2 over the owned planes. */
 int fdtd_energy(fdtd_ctx* ctx, double sums[2]);

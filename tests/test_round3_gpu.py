@@ -221,3 +221,54 @@ def test_schedule_info_tells_the_schedule(hip_lib):
     assert info["launches_per_timestep"] == 3 and not info["xcd_shares_weighted"]
     s = patch_sim(48, 44, 30, boundary="PEC", nr_ts=10)
     assert s.build(hip_lib).schedule_info()["launches_per_timestep"] == 2     # small grid without CPML: two launches
+
+
+def test_measured_xcd_shares_leave_the_results_alone(hip_lib, oracle_lib, monkeypatch):
+    """The last launch of an fdtd_run call of >= 16 timesteps is a calibration launch (every block leaves its end time) and
+    the shares of the eight XCDs are re-cut from the measured finish times: the cuts move between the calls of one run,
+    the fields may not.  Ten calls on the GPU against one run on the oracle, and against a context that never adapts."""
+    capi = pkg("_capi")
+    s = patch_sim(64, 60, 36, nr_ts=400)
+    e = s.build(hip_lib)
+    for _ in range(10):
+        e.run(32)
+    info = e.schedule_info()
+    assert info["launches_per_timestep"] == 1 and info["xcd_adaptations"] >= 8
+    so = patch_sim(64, 60, 36, nr_ts=400)
+    eo = so.build(oracle_lib)
+    eo.run(320)
+    assert np.array_equal(e.fields(), eo.fields())
+    assert rel_l2(s.port_series()[0][0], so.port_series()[0][0]) < 1e-12
+    monkeypatch.setenv("FDTD_XCD_ADAPT", "0")
+    s0 = patch_sim(64, 60, 36, nr_ts=400)
+    e0 = s0.build(hip_lib)
+    for _ in range(10):
+        e0.run(32)
+    assert e0.schedule_info()["xcd_adaptations"] == 0 and np.array_equal(e0.fields(), e.fields())
+
+
+@pytest.mark.parametrize("shape,bc", [((64, 60, 36), "CPML"), ((53, 47, 31), "CPML"), ((260, 18, 40), "CPML"), ((64, 60, 36), "PEC")])
+def test_several_timesteps_per_launch_equal_one_per_launch(hip_lib, oracle_lib, shape, bc, monkeypatch):
+    """Cache-resident single slabs step SEVERAL timesteps per launch (k_step<.., MULTI>: the E blocks of timestep s + 1 wait
+    for the flags of the H blocks of timestep s; device-scope loads and write-through stores for fields and psi; launches cut
+    at the timesteps whose NF2FF faces are sampled).  Against one launch per timestep ($FDTD_WF_MULTI=1) and against the
+    oracle: fields, port series (the probe blocks of every timestep inside the launch) and the recorded NF2FF faces, over
+    calls of 1, 7, 100 and 61 timesteps from seeded fields."""
+    capi = pkg("_capi")
+    out = []
+    for multi, lib in (("64", hip_lib), ("1", hip_lib), ("64", oracle_lib)):
+        monkeypatch.setenv("FDTD_WF_MULTI", multi)
+        s = patch_sim(*shape, boundary=bc, cpml_cells=6, nr_ts=200, nf2ff_mode="record")
+        e = s.build(lib, flags=capi.FLAG_KERNEL_WAVEFRONT if lib is hip_lib else 0)
+        if lib is hip_lib:
+            assert e.schedule_info()["timesteps_per_launch_max"] == int(multi)
+        seeded_fields(e, 17)
+        for n in (1, 7, 100, 61):
+            e.run(n)
+        out.append((e.fields(), s.port_series()[0], s.nf2ff_boxes()))
+    (fm, pm, bm), (f1, p1, b1), (fo, po, bo) = out
+    assert np.abs(fo).max() > 0 and np.array_equal(fm, f1) and np.array_equal(fm, fo)
+    assert np.array_equal(pm[0], p1[0]) and np.array_equal(pm[1], p1[1])
+    assert rel_l2(pm[0], po[0]) < 1e-12 and rel_l2(pm[1], po[1]) < 1e-12
+    for a, b, c in zip(bm, b1, bo):
+        assert np.array_equal(a, b) and rel_l2(a, c) < 1e-12

@@ -52,6 +52,8 @@ def main():
             # nothing is timed before the pulse has reached every corner of the grid: the step time depends on the field values
             # (all-zero fields stream 6-15 % faster, profiles/r02/step_time_vs_field_values.txt)
             eng.run(max(steps // 2, 2 * max(w.grid.shape)))
+            for _ in range(int(os.environ.get("AB_WARM_CALLS", "8"))):     # the XCD shares settle over the first fdtd_run calls of a context
+                eng.run(64)
             t0 = time.perf_counter()
             eng.run(steps)
             dt = time.perf_counter() - t0
