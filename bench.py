@@ -239,13 +239,20 @@ def roofline_block(workload, eng, prof, world, host_transport, ms_timestep):
                 "traffic": None, "kernel": dom, "algorithmic_bytes_per_launch": algo_bytes}
     achieved = algo_bytes / (ms_dom * 1e-3) / 1e9
     ms_ts = prof.ms_total / prof.steps
+    # one launch may hold several timesteps (cache-resident single slabs): ms_update_E is the main-launch time PER TIMESTEP
+    # (the launches' durations summed, over the timesteps), the bytes are per timestep too; a kernel trace shows the launches
+    launches = int(getattr(prof, "launches_e", 0)) or int(prof.steps)
+    ts_per_launch = prof.steps / launches if one_launch else 1.0
     traffic, source = pmc_traffic(workload, dom, world)
     ws = working_set_bytes(eng)
     out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
            "traffic_source": source, "kernel": dom, "ms_update_E": round(ms_e, 5), "ms_update_H": round(ms_h, 5),
-           "algorithmic_bytes_per_launch": algo_bytes,
-           "schedule": ("one launch per timestep (k_step: all E blocks, then all H blocks; beyond the Infinity Cache the H sweep a few planes behind the E sweep)"
+           "algorithmic_bytes_per_launch": algo_bytes * ts_per_launch, "algorithmic_bytes_per_timestep": algo_bytes,
+           "timesteps_per_launch": round(ts_per_launch, 2), "ms_per_launch": round(ms_dom * ts_per_launch, 5),
+           "schedule": (("k_step: all E blocks, then all H blocks of a timestep; several timesteps per launch (cut where the NF2FF faces are sampled)"
+                         if ts_per_launch > 1.0 else
+                         "one launch per timestep (k_step: all E blocks, then all H blocks; beyond the Infinity Cache the H sweep a few planes behind the E sweep)")
                         if one_launch else "two launches per timestep"),
            "kernel_timing": "dispatch begin/end timestamps (start/stop events on every main launch), nothing subtracted",
            "ms_per_timestep_profiled": round(ms_ts, 5),
