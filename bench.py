@@ -306,10 +306,12 @@ def pmc_traffic(workload, kernel, world):
         return None, None
     try:
         data = json.load(open(files[-1]))["per_launch_traffic"]
-        for name, rec in data.items():
-            if kernel.replace("update_", "k_update_").replace("step", "k_step") in name:
-                return round(rec["total_bytes"]), ("committed rocprofv3 --pmc passes, not measured in this run: "
-                                                   + os.path.relpath(files[-1], ROOT))
+        want = kernel.replace("update_", "k_update_").replace("step", "k_step")
+        # per TIMESTEP, like `achieved`: the launches that hold several timesteps first (their bytes over their timesteps)
+        for name, rec in sorted(data.items(), key=lambda kv: "total_bytes_per_timestep" not in kv[1]):
+            if want in name:
+                return round(rec.get("total_bytes_per_timestep", rec["total_bytes"])), (
+                    "committed rocprofv3 --pmc passes (bytes per timestep), not measured in this run: " + os.path.relpath(files[-1], ROOT))
     except (OSError, KeyError, ValueError):
         pass
     return None, None

@@ -382,8 +382,19 @@ int fdtd_set_cpml(fdtd_ctx* c, const int32_t* sx, const int32_t* sy, const int32
     HIPCK(c, hipMemcpy(c->xc_tab, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
     c->p.xc_tab = c->xc_tab;
   }
-  // psi: axis x -> [nk][ny][nsx]; y -> [nk][nsy][P]; z -> [nsz][ny][P]
-  const size_t psz[3] = {(size_t)nk * ny * c->p.nslot[0], (size_t)nk * nsy * P, (size_t)nsz * ny * P};
+  // psi: axis x -> rows of xrs floats per (k, j); y -> [nk][nsy][P]; z -> [nsz][ny][P].
+  // x rows: a wave that straddles a row boundary holds the three lanes at the end of row j - 1 (high layer) and the three at the
+  // start of row j (low layer); row j of the psi arrays holds exactly those 24 values, on a 128-byte line of its own (xrs = 32 floats):
+  // one line per wave and array instead of pieces of two lines shared with the neighbouring waves — what write-through stores
+  // (several timesteps per launch) need: NS x-layers +7.7 -> +x.x us.  $FDTD_XPSI_PACKED=1: rows of nslot floats back to back.
+  {
+    DevParams& q = c->p;
+    const int lo4 = q.pml_lo[0], hs = q.pml_hi[0] < (1 << 30) ? P - q.pml_hi[0] : 0;
+    if (getenv("FDTD_XPSI_PACKED")) { q.xrs = q.nslot[0]; q.xplane = ny * q.xrs; q.xlo_off = 0; q.xhi_off = lo4; }
+    else { q.xrs = (q.nslot[0] + 31) / 32 * 32; q.xplane = (ny + 1) * q.xrs; q.xlo_off = hs; q.xhi_off = q.xrs; }
+    if ((long)nk * q.xplane >= (1L << 30)) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "x-directed psi arrays exceed 2^30 elements: use more z-slabs");
+  }
+  const size_t psz[3] = {(size_t)nk * c->p.xplane + (size_t)c->p.xrs, (size_t)nk * nsy * P, (size_t)nsz * ny * P};
   for (int n = 0; n < 12; ++n) { hipFree(c->psi[n]); c->psi[n] = nullptr; }
   for (int eh = 0; eh < 2; ++eh)
     for (int comp = 0; comp < 3; ++comp)

@@ -75,6 +75,8 @@ struct DevParams {
   // CPML: index q along axis a is in a layer iff q < pml_lo[a] (slot q) or q >= pml_hi[a]
   // (slot q - pml_hi[a] + pml_hi_slot[a]); pml_hi[a] >= n_a disables the upper layer.
   int pml_lo[3], pml_hi[3], pml_hi_slot[3], nslot[3];
+  // x-directed psi: element offset of (k, j, i0) = k * xplane + j * xrs + (i0 < pml_lo[0] ? xlo_off + i0 : xhi_off + i0 - pml_hi[0])
+  int xrs, xplane, xlo_off, xhi_off;
   const float* cp[3][2][3];  // [axis][E-loc/H-loc][b, c, 1/kappa]
   const float* xc_tab;       // [E-loc/H-loc][b, c, 1/kappa][XC_MAX]: the x-layer cells' coefficients in psi-slot order (null: more than XC_MAX)
   float* psiE[3][2];

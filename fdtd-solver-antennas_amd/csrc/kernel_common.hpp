@@ -428,7 +428,7 @@ __device__ __forceinline__ void cpml_row4_reg(float4& d, float4& ps, float b, fl
   d.w = __builtin_fmaf(ik, d.w, ps.w);
 }
 
-// x-directed layers: per-cell coefficients, psi stored [k][j][nslot_x].  Both x ranges of the internal layout start on a
+// x-directed layers: per-cell coefficients, psi stored in rows of xrs floats per (k, j) (psi_off_x).  Both x ranges of the internal layout start on a
 // 4-cell boundary (fdtd_set_cpml), so a thread's four cells are ONE aligned float4 of psi and of each coefficient table
 // (cells drawn into the aligned range from outside the real layer, and pad cells, carry identity coefficients).
 __device__ __forceinline__ void cpml_x4_apply(float4& d, float4& ps, const float4& b, const float4& c, const float4& ik) {
@@ -443,7 +443,7 @@ __device__ __forceinline__ void cpml_x4_apply(float4& d, float4& ps, const float
 }
 __device__ __forceinline__ void cpml_x4(const DevParams& p, int eh, int i0, int rowslot, float4& da, float* psia,
                                         float4& db, float* psib) {
-  const int sx = i0 < p.pml_lo[0] ? i0 : i0 - p.pml_hi[0] + p.pml_hi_slot[0];
+  const int sx = i0 < p.pml_lo[0] ? p.xlo_off + i0 : p.xhi_off + i0 - p.pml_hi[0];
   const float4 b = ld4(p.cp[0][eh][0] + i0), c = ld4(p.cp[0][eh][1] + i0), ik = ld4(p.cp[0][eh][2] + i0);
   float* qa = psia + rowslot + sx;
   float* qb = psib + rowslot + sx;
@@ -462,9 +462,12 @@ __device__ __forceinline__ int psi_off_x(const DevParams& p, const int k, const 
   // addend, picks a register a field load is still in flight to for it, and guards that false dependency with
   // s_waitcnt vmcnt(0) — in front of the staged psi loads, i.e. every wave with an x-layer lane (all of them) waited for its
   // field loads before it issued its psi loads
-  int row = (k * p.ny + j) * p.nslot[0];
+  // layout (fdtd_set_cpml): one 128-byte-aligned row of xrs floats per (k, j), holding the HIGH part of row j - 1 and then the
+  // LOW part of row j — the lanes of a wave that straddles a row boundary (end of row j - 1, start of row j) read and write
+  // ONE cache line of each psi array, and no other wave touches it
+  int row = k * p.xplane + j * p.xrs;
   asm volatile("" : "+v"(row));
-  return row + (i0 < p.pml_lo[0] ? i0 : i0 - p.pml_hi[0] + p.pml_hi_slot[0]);
+  return row + (i0 < p.pml_lo[0] ? p.xlo_off + i0 : p.xhi_off + i0 - p.pml_hi[0]);
 }
 __device__ __forceinline__ int psi_off_z(const DevParams& p, const int k, const int j, const int i0) {
   const int sz = pml_slot(p, 2, k);

@@ -211,7 +211,7 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
         cpml_row4(dy1, p.psiE[1][0], (unsigned)o, b, c, ik);
       }
       if (i0 < p.pml_lo[0] || i0 >= p.pml_hi[0])   // both bounds are multiples of 4: all four cells or none
-        cpml_x4(p, 0, i0, (k * p.ny + j) * p.nslot[0], dy2, p.psiE[1][1], dz1, p.psiE[2][0]);
+        cpml_x4(p, 0, i0, k * p.xplane + j * p.xrs, dy2, p.psiE[1][1], dz1, p.psiE[2][0]);
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the coefficient loads of the update below out of the CPML section (registers)
   }
@@ -430,7 +430,7 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
         cpml_row4(dy1, p.psiH[1][0], (unsigned)o, b, c, ik);
       }
       if (i0 < p.pml_lo[0] || i0 >= p.pml_hi[0])
-        cpml_x4(p, 1, i0, (k * p.ny + j) * p.nslot[0], dy2, p.psiH[1][1], dz1, p.psiH[2][0]);
+        cpml_x4(p, 1, i0, k * p.xplane + j * p.xrs, dy2, p.psiH[1][1], dz1, p.psiH[2][0]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }

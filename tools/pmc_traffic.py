@@ -12,6 +12,7 @@ import csv, glob, json, os, subprocess, sys, collections
 wl, out = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 raw = collections.defaultdict(dict)
+timesteps_total = None
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(root, "gpurun_out", f"pmc_{wl}_{ctr}")
     subprocess.run(["rm", "-rf", d])
@@ -22,6 +23,9 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-2000:])
         raise SystemExit(f"rocprofv3 failed for {ctr}")
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            timesteps_total = json.loads(line)["config"]["timesteps_total"]
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no counter csv under {d}")
@@ -36,11 +40,16 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in acc.items():
         raw[k][ctr] = {"launches": len(v), "mean": sum(v) / len(v)}
 per = {}
+# launches of k_step<.., true> hold several timesteps: their traffic per TIMESTEP = per launch / (timesteps they stepped / launches)
+single = sum(v["FETCH_SIZE"]["launches"] for k, v in raw.items() if "k_step" in k and k.rstrip().endswith("false>") and "FETCH_SIZE" in v)
 for k, v in raw.items():
     if ("k_update" in k or "k_step" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         rd = v["FETCH_SIZE"]["mean"] * 1024.0 * 2.0      # KiB, x2 gfx950 correction
         wr = v["WRITE_SIZE"]["mean"] * 1024.0
         per[k] = {"read_bytes_corrected": rd, "write_bytes": wr, "total_bytes": rd + wr}
+        if "k_step" in k and k.rstrip().endswith("true>") and timesteps_total:
+            tsl = (timesteps_total - single) / v["FETCH_SIZE"]["launches"]
+            per[k].update({"timesteps_per_launch": tsl, "total_bytes_per_timestep": (rd + wr) / tsl})
 json.dump({"raw": raw, "per_launch_traffic": per, "workload": wl,
            "note": "separate --pmc passes; FETCH_SIZE x2 (gfx950 correction); KiB units; tools/pmc_traffic.py"}, open(out, "w"), indent=1)
 print(json.dumps(per, indent=1))
