@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--workload", default="NS")
     ap.add_argument("--ts-per-step", type=int, default=500)
     ap.add_argument("--cpml-cells", type=int, default=10)
+    ap.add_argument("--prefill-seconds", type=float, default=2.5,
+                    help="untimed stepping before the warm-up steps, as a number of timesteps fixed by the grid size (seconds x 75 Gcells/s / cells): "
+                         "the pulse fills the grid and the GPU leaves its idle clocks (0: only twice the longest axis)")
     ap.add_argument("--halo", default="auto", choices=["auto", "p2p", "rccl", "host"],
                     help="N > 1: halo transport (auto = P2P mailbox, then RCCL, then host copies)")
     ap.add_argument("--partition", default="cost", choices=["cost", "even"],
@@ -94,7 +97,10 @@ def main():
     # Untimed pre-fill on top of the W warm-up steps: the step time depends on the field VALUES (all-zero fields stream 6-15 %
     # faster, profiles/r02/step_time_vs_field_values.txt), so nothing is timed before the pulse has reached every corner of
     # the grid (<= 0.58 cells per timestep at the Courant limit: twice the longest axis in timesteps)
-    prefill = 2 * max(w.grid.shape)
+    # ... and a GPU that has idled (process start, the 10 s CPU leg above) steps up to 10 % slower for its first second or two
+    # (profiles/r03/README.md: one default run of this file at 74.9 us per timestep, the same command minutes later at 67.3): the
+    # pre-fill lasts ~--prefill-seconds of GPU time, as a timestep count that depends on the grid size only (the same for every N)
+    prefill = max(2 * max(w.grid.shape), int(args.prefill_seconds * 75e9 / w.grid.ncells))
     nts_total = (args.steps + args.warmup) * args.ts_per_step * 2 + prefill + 8
     sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=args.cpml_cells,
                           nr_ts=nts_total, nf2ff_freqs=[w.f0], nf2ff_mode="auto", use_classes=not args.raw_operator)

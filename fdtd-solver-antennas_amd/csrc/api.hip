@@ -386,7 +386,8 @@ int fdtd_set_cpml(fdtd_ctx* c, const int32_t* sx, const int32_t* sy, const int32
   // x rows: a wave that straddles a row boundary holds the three lanes at the end of row j - 1 (high layer) and the three at the
   // start of row j (low layer); row j of the psi arrays holds exactly those 24 values, on a 128-byte line of its own (xrs = 32 floats):
   // one line per wave and array instead of pieces of two lines shared with the neighbouring waves — what write-through stores
-  // (several timesteps per launch) need: NS x-layers +7.7 -> +x.x us.  $FDTD_XPSI_PACKED=1: rows of nslot floats back to back.
+  // (several timesteps per launch) need: north-star grid with the x layers alone 62.6 -> 60.9 us per timestep (profiles/r03/x_psi_rows_on_lines_ab.txt).
+  // $FDTD_XPSI_PACKED=1: rows of nslot floats back to back (the round-2 layout).
   {
     DevParams& q = c->p;
     const int lo4 = q.pml_lo[0], hs = q.pml_hi[0] < (1 << 30) ? P - q.pml_hi[0] : 0;

@@ -982,10 +982,17 @@ int xcd_adapt(fdtd_ctx* c) {
     mean += T[x] / 8.0;
   }
   if (mode != 1) return FDTD_OK;
+  // one launch is one sample: a share that finished more than 25 % off the mean is an event (a pre-empted XCD, a page fault),
+  // not a property of the chip — drop the sample; and no single correction moves a share by more than 6 %
+  for (int x = 0; x < 8; ++x) if (T[x] < 0.8 * mean || T[x] > 1.25 * mean) return FDTD_OK;
   double (&f)[8] = c->xfrac;
   const double gain = c->xcd_adapt_done < 2 ? 0.75 : 0.4;
   double sum = 0.0;
-  for (int x = 0; x < 8; ++x) { f[x] = std::min(0.25, std::max(0.0625, f[x] * std::pow(mean / T[x], gain))); sum += f[x]; }
+  for (int x = 0; x < 8; ++x) {
+    const double corr = std::min(1.06, std::max(0.94, std::pow(mean / T[x], gain)));
+    f[x] = std::min(0.25, std::max(0.0625, f[x] * corr));
+    sum += f[x];
+  }
   for (int x = 0; x < 8; ++x) f[x] /= sum;
   c->xcd_adapt_done++;
   xcd_shares_reset(c);

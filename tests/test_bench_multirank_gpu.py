@@ -14,7 +14,8 @@ import pytest
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
-ARGS = ["--steps", "2", "--warmup", "1", "--ts-per-step", "100", "--workload", "C2", "--no-cpu-baseline", "--no-hbm-point"]
+ARGS = ["--steps", "2", "--warmup", "1", "--ts-per-step", "100", "--workload", "C2", "--no-cpu-baseline", "--no-hbm-point",
+        "--prefill-seconds", "0"]
 
 
 def _free_port():
@@ -58,6 +59,19 @@ def test_bench_under_torchrun_couples_the_ranks(single, nranks, halo):
     assert mg["transport_used"] == ("p2p" if halo in ("p2p", "auto") else "host")
     assert f"z-slab x{nranks}" in out["config"]["parallelism"] and mg["transport_used"] in out["config"]["parallelism"]
     assert sum(r["slab_planes"] for r in mg["per_rank"]) == 40
+    # the record describes itself: partition, per-rank planes / z-layer planes / time / schedule, and (p2p) what the runtime knows
+    # about the way to each neighbour's GPU — here every rank sits on device 0
+    assert mg["partition"] == "cost" and mg["z_layer_plane_cost"] == 1.5 and mg["rank_time_max_over_mean"] >= 1.0
+    assert sum(r["slab_z_cpml_planes"] for r in mg["per_rank"]) == 21 and [r["slab_k0"] for r in mg["per_rank"]][0] == 0
+    assert all(r["launches_per_timestep"] in (0, 1, 2) and r["us_per_timestep"] > 0 for r in mg["per_rank"])
+    if mg["transport_used"] == "p2p":
+        for r in mg["per_rank"]:
+            assert r["launches_per_timestep"] == 2 and r["ms_p2p_selftest"] > 0
+            links = [l for l in (r["link_down"], r["link_up"]) if l is not None]
+            assert len(links) == (2 if 0 < r["rank"] < nranks - 1 else 1)
+            assert all(l["same_device"] and l["device"] == 0 and l["mapping"] == "ipc" for l in links)
+        if nranks == 3:
+            assert [r["slab_planes"] for r in mg["per_rank"]][1] > mg["per_rank"][0]["slab_planes"]
     assert mg["all_slabs_excited"]                      # slabs without the port are non-zero only through their halos
     assert mg["rccl_nranks"] == 0                       # no RCCL communicator on the shared device
     if halo == "host":

@@ -272,3 +272,34 @@ def test_several_timesteps_per_launch_equal_one_per_launch(hip_lib, oracle_lib, 
     assert rel_l2(pm[0], po[0]) < 1e-12 and rel_l2(pm[1], po[1]) < 1e-12
     for a, b, c in zip(bm, b1, bo):
         assert np.array_equal(a, b) and rel_l2(a, c) < 1e-12
+
+
+# ---- GPU twins of the host-layer known-answer tests (tests/test_host_layer_kat_cpu.py): the same closed-form answers with
+# ---- libfdtd_hip.so as the engine, and the engine's numbers equal to the oracle's
+def test_microstrip_line_kat_on_the_gpu(hip_lib, oracle_lib, tmp_path):
+    import test_host_layer_kat_cpu as kat
+    pd = pkg("patch_design")
+    f = np.linspace(1.0e9, 2.0e9, 11)
+    res = {}
+    for length in (30.0, 50.0):
+        fdtd, p1, p2, W = kat._microstrip_line(hip_lib, str(tmp_path / f"g{int(length)}"), length, 4.3, 1.6, nr_ts=5000)
+        res[length] = kat._abcd_of_line(p1, p2, f)
+        if length == 30.0:      # engine parity on this scene (graded mesh, Mur faces, two lumped ports)
+            _, o1, o2, _ = kat._microstrip_line(oracle_lib, str(tmp_path / "o30"), length, 4.3, 1.6, nr_ts=5000)
+            zo, blo, _ = kat._abcd_of_line(o1, o2, f)
+            assert rel_l2(p1.u_data.ui_val[0], o1.u_data.ui_val[0]) < 1e-9 and rel_l2(p2.i_data.ui_val[0], o2.i_data.ui_val[0]) < 1e-9
+            assert rel_l2(res[30.0][0], zo) < 1e-6
+    z0 = res[30.0][0]
+    assert np.all(np.abs(z0.real - 50.0) < 2.5) and np.all(np.abs(z0.imag) < 1.0), z0
+    eps_eff = ((res[50.0][1] - res[30.0][1]) / 20e-3 * kat.C0 / (2 * np.pi * f)) ** 2
+    assert np.all(np.abs(eps_eff / pd.effective_eps(4.3, 1.6e-3, W * 1e-3) - 1.0) < 0.03), eps_eff
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_cpml_terminating_a_dielectric_on_the_gpu(hip_lib, half):
+    import test_host_layer_kat_cpu as kat
+    n, steps, off = 64, 700, 230
+    small = kat._plate_line(hip_lib, n, n, "CPML", steps, (32, 32), (40, 27), 4.3, half)
+    big = kat._plate_line(hip_lib, n + 2 * off, n + 2 * off, "PEC", steps, (32 + off, 32 + off), (40 + off, 27 + off), 4.3, half)
+    err = np.max(np.abs(small - big)) / np.max(np.abs(big))
+    assert 20 * np.log10(err) < -60.0, f"reflection {20 * np.log10(err):.1f} dB"
