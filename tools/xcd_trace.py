@@ -1,4 +1,4 @@
-"""Per-XCD timing of ONE k_step launch (diagnostic build of the library with -DFDTD_XCD_TRACE: scratch/build_variant.sh trace
+"""Per-XCD timing of ONE k_step launch (diagnostic build of the library with -DFDTD_XCD_TRACE: tools/build_variant.sh trace
 -DFDTD_XCD_TRACE): for every XCD (by HW_REG_XCC_ID) the first start and last end of its E blocks and of its H blocks, relative
 to the launch's first block, and how many blocks it ran — what the cost-weighted XCD shares are supposed to equalise.
 
