@@ -6,7 +6,9 @@
 //      k_post is the stand-alone form used with Mur boundaries and by fdtd_half_step     (N4, N8)
 //   K4 k_mur        first-order Mur pre / post / apply on the six faces   (N6)
 //   K6 k_dft        running DFT of field boxes (NF2FF surfaces)           (N9)
-//   K8 k_energy     sum V^2, sum I^2                                      (N11)
+//   K8 k_energy     sum V^2, sum I^2 (per-block partials, added in block order)   (N11)
+//   K1+K2 k_step    both half-steps of a timestep in ONE launch behind per-block flags; on cache-resident
+//                   single slabs SEVERAL timesteps per launch (device-scope loads / write-through stores)
 //
 // These replace what the reference runs inside FDTD.Run(...) of the external openEMS engine
 // (antenna_sim/solver_fdtd_openems_fixed.py:280 and the four sibling call sites).
@@ -19,7 +21,8 @@
 //     scene has more than 256 distinct edge-class triples) indexes a (vv, m) table staged in LDS, the
 //     mesh metric comes from 1-D tables in L1;
 //   * blockIdx is remapped so that each XCD (own 4 MiB L2) sweeps one contiguous part of the slab,
-//     ordered strip-by-strip through z so the k+-1 and j+-1 neighbour rows are L2 hits;
+//     ordered strip-by-strip through z so the k+-1 and j+-1 neighbour rows are L2 hits; the eight parts
+//     are equal in COST (CPML rows / planes weigh more), then corrected by measured finish times;
 //   * CPML psi arrays exist only inside the layers; interior threads pay three compares.
 //
 // Float32 operation order is pinned with explicit fmaf (compiled with -ffp-contract=off) and is
