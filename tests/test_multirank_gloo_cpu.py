@@ -69,3 +69,40 @@ def test_ranks_equal_one(oracle_lib, tmp_path, world):
             assert np.allclose(q[f"box{n}"], b, rtol=1e-12, atol=1e-30)
     sv, si = e.energy()
     assert np.allclose(r[0]["en"], [sv, si], rtol=1e-12)
+
+
+def _worker_api(rank, world, port, out_dir):
+    """The plugin-level path: openems_api.openEMS(rank=, world=, comm=) — Run() on every rank, post-processing on rank 0 ALONE."""
+    import ctypes
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import tutorial_scene
+    lib = pkg("_capi").bind(ctypes.CDLL(os.path.join(ROOT, "oracle", "libfdtd_oracle.so")))
+    comm = pkg("distributed").SlabComm(transport="auto")
+    r = tutorial_scene.build_and_run(lib, os.path.join(out_dir, f"run{rank}"), nr_ts=400, end_criteria=0, f_ff=2e9, post=(rank == 0),
+                                     rank=rank, world=world, comm=comm)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "api_rank0.npz"), s11=r["s11"], Dmax=r["Dmax"], E=r["E_norm"], u=r["u"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_plugin_level_two_ranks_postprocess_on_rank_zero_alone(oracle_lib, tmp_path):
+    """in record mode the cross-rank reduction of the NF2FF faces had moved into CalcNF2FF, which made it a
+    collective — a caller that post-processes on rank 0 only hung.  Run() now reduces the faces for the excitation's centre
+    frequency where every rank is; CalcNF2FF(f0) and CalcPort on rank 0 alone return, and equal the single-rank run."""
+    import torch.multiprocessing as mp
+    import tutorial_scene
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker_api, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    two = np.load(tmp_path / "api_rank0.npz")
+    one = tutorial_scene.build_and_run(oracle_lib, str(tmp_path / "single"), nr_ts=400, end_criteria=0, f_ff=2e9)
+    assert one["nf2ff_mode"] == "record"
+    assert np.allclose(two["u"], one["u"], rtol=1e-12, atol=0) and np.allclose(two["s11"], one["s11"], rtol=1e-9)
+    assert abs(float(two["Dmax"]) - one["Dmax"]) < 1e-9 * one["Dmax"] and np.allclose(two["E"], one["E_norm"], rtol=1e-9)

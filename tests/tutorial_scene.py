@@ -10,7 +10,9 @@ import numpy as np
 from conftest import pkg
 
 
-def build_and_run(lib, sim_path, nr_ts=60000, end_criteria=1e-5, verbose=0):
+def build_and_run(lib, sim_path, nr_ts=60000, end_criteria=1e-5, verbose=0, f_ff=None, post=True, **fdtd_kw):
+    """f_ff: evaluate the far field THERE instead of at the S11 dip; post=False: Run() only (a rank that leaves the
+    post-processing to rank 0); fdtd_kw: backend options of openems_api.openEMS (rank=, world=, comm=, ...)."""
     oa = pkg("openems_api")
     C0, EPS0 = oa.physical_constants.C0, oa.physical_constants.EPS0
     patch_w, patch_l = 32.0, 40.0                 # mm: x (resonant), y
@@ -18,7 +20,7 @@ def build_and_run(lib, sim_path, nr_ts=60000, end_criteria=1e-5, verbose=0):
     feed_x, feed_R = -6.0, 50.0
     box = np.array([200.0, 200.0, 150.0])
     f0, fc = 2e9, 1e9
-    fdtd = oa.openEMS(NrTS=nr_ts, EndCriteria=end_criteria, lib=lib)
+    fdtd = oa.openEMS(NrTS=nr_ts, EndCriteria=end_criteria, lib=lib, **fdtd_kw)
     fdtd.SetGaussExcite(f0, fc)
     fdtd.SetBoundaryCond([3] * 6)
     csx = oa.ContinuousStructure()
@@ -44,6 +46,8 @@ def build_and_run(lib, sim_path, nr_ts=60000, end_criteria=1e-5, verbose=0):
     mesh.SmoothMeshLines("all", res, 1.4)
     nf2ff = fdtd.CreateNF2FFBox()
     fdtd.Run(sim_path, verbose=verbose, cleanup=True)
+    if not post:
+        return {"steps": fdtd.stats.steps}
     # post-processing of the tutorial: S11 over f0 +- fc, far field at the dip
     f = np.linspace(max(1e9, f0 - fc), f0 + fc, 401)
     port.CalcPort(sim_path, f)
@@ -51,7 +55,7 @@ def build_and_run(lib, sim_path, nr_ts=60000, end_criteria=1e-5, verbose=0):
     s11_dB = 20 * np.log10(np.abs(s11))
     k = int(np.argmin(s11_dB))
     theta = np.arange(0.0, 181.0, 2.0)
-    ff = nf2ff.CalcNF2FF(sim_path, f[k], theta, [0.0, 90.0], center=[0.0, 0.0, 1e-3])
+    ff = nf2ff.CalcNF2FF(sim_path, f[k] if f_ff is None else f_ff, theta, [0.0, 90.0], center=[0.0, 0.0, 1e-3])
     return {"f": f, "s11": s11, "s11_dB": s11_dB, "f_dip": float(f[k]), "dip_dB": float(s11_dB[k]),
             "Dmax": float(np.asarray(ff.Dmax)[0]), "E_norm": np.asarray(ff.E_norm[0]), "theta": theta,
             "grid": fdtd.sim.grid.shape, "steps": fdtd.stats.steps, "energy_db": float(fdtd.stats.energy_db),
