@@ -159,6 +159,24 @@ __global__ __launch_bounds__(256) void k_fused_flags(const Arr a, const int m, c
   }
 }
 
+// T timesteps in ONE launch as a space-time wavefront along z (round 3 question: would grids beyond the Infinity Cache gain if
+// SEVERAL timesteps shared one pass over HBM?): per XCD and plane group g the dispatch order is
+//   E_0(g), H_0(g - lag), E_1(g - 2 lag), H_1(g - 3 lag), ... , H_{T-1}(g - (2T-1) lag)
+// — no dependencies (data movement only), every access sc1.  Odd launches walk the planes downwards.
+__global__ __launch_bounds__(256) void k_fused_T(const Arr a, const int m, const int nz, const size_t plane4, const int lag, const int T, const int down) {
+  const unsigned b = blockIdx.x, x = b & 7u, pos = b >> 3;
+  const unsigned per = (unsigned)(2 * T * m);
+  const unsigned grp = pos / per, w = pos - grp * per;
+  const unsigned role = w / (unsigned)m, r = w - role * (unsigned)m;
+  int k = (int)grp - (int)role * lag;
+  if (k < 0 || k >= nz) return;
+  if (down) k = nz - 1 - k;
+  const size_t in_plane = (size_t)(x * m + r) * 256 + threadIdx.x;
+  if (in_plane >= plane4) return;
+  const size_t idx = (size_t)(k + 1) * plane4 + in_plane;
+  if (!(role & 1u)) body_E<true>(a, idx, plane4); else body_H<true>(a, idx, plane4);
+}
+
 int main(int argc, char** argv) {
   struct { const char* name; int nx, ny, nz; } grids[] = {{"NS", 300, 300, 60}, {"C3", 400, 400, 80}, {"C4", 512, 512, 128}, {"C5", 800, 800, 120}};
   const int reps = 30;
@@ -213,6 +231,21 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         char tag[64]; snprintf(tag, sizeof tag, "one launch lag %2d %s", lag, variant == 0 ? "no deps" : variant == 1 ? "plane cnt" : variant == 2 ? "plane cnt + sc1" : variant == 3 ? "no deps + sc1" : variant == 4 ? "block flags + sc1" : "block flags, plain (racy)");
         report(tag, ms);
+      }
+    }
+    for (int T : {1, 2, 3, 4}) {      // space-time wavefront, no dependencies
+      for (int lag : {2, 4, 6, 8, 12}) {
+        if ((2 * T - 1) * lag >= 2 * g.nz) continue;
+        const unsigned grid = 8u * 2u * T * m * (g.nz + (2 * T - 1) * lag);
+        const int nl = (reps + T - 1) / T;
+        for (int it = -2; it < nl; ++it) {
+          if (it == 0) hipEventRecord(e0);
+          hipLaunchKernelGGL(k_fused_T, dim3(grid), dim3(256), 0, 0, a, m, g.nz, plane4, lag, T, it & 1);
+        }
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        char tag[64]; snprintf(tag, sizeof tag, "wavefront T=%d lag %2d no deps + sc1", T, lag);
+        report(tag, ms * reps / (float)(nl * T));
       }
     }
     for (int c = 0; c < 3; ++c) { hipFree(a.V[c]); hipFree(a.I[c]); }
