@@ -126,7 +126,11 @@ def main():
             torch.cuda.synchronize()
 
     tps = args.ts_per_step
-    run_steps(prefill)
+    done = 0
+    while done < prefill:                  # in calls of at most 2000 timesteps (a decomposed grid enqueues two launches per timestep)
+        n = min(2000, prefill - done)
+        run_steps(n)
+        done += n
     for _ in range(args.warmup):
         run_steps(tps)
     barrier()
