@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--halo", default="auto", choices=["auto", "p2p", "rccl", "host"],
                     help="N > 1: halo transport (auto = P2P mailbox, then RCCL, then host copies)")
     ap.add_argument("--partition", default="cost", choices=["cost", "even"],
-                    help="N > 1: z-slabs of equal cost (the z-CPML planes weigh 1.5: the end ranks own fewer planes) or of equal plane count")
+                    help="N > 1: z-slabs of equal cost (the z-CPML planes weigh 1.4: the end ranks own fewer planes) or of equal plane count")
     ap.add_argument("--raw-operator", action="store_true", help="stream 12 coefficient arrays instead of class bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the C3 (HBM-resident) roofline block")

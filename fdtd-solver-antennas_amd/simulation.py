@@ -31,11 +31,13 @@ def slab_range(nz: int, world: int, rank: int):
 
 
 # A z-plane inside a z-directed CPML layer reads and writes four more psi arrays per timestep (+16 of 37 bytes per cell and
-# half-step) than a plane outside: measured on MI355X it costs 1.5x as much (NS: 20 layer planes +10.4 us over 60 planes of
+# half-step) than a plane outside: measured on MI355X it costs 1.3-1.55x as much (NS: 20 layer planes +10.4 us over 60 planes of
 # 0.95 us; C3: +18.0 us over 80 planes of 1.78 us — profiles/r02/cpml_axis_cost.txt; per-slab times: profiles/r03/slab_balance.txt).
 # With planes counted alike the first and the last rank, which own ALL layer planes, take up to 37 % longer than the interior
 # ranks (C5 on 8 GPUs: 10 of their 15 planes), and every rank waits for its neighbours' halos each half-step.
-Z_LAYER_PLANE_COST = float(os.environ.get("FDTD_SLAB_WZ", "1.5"))
+# (weight: each slab timed alone, profiles/r03/slab_balance*.txt — 1.4 leaves max / mean at 1.03 (NS over 8), 1.06 (C4 over 4), 1.03 (C5 over 8);
+# 1.5 is better for C4 (1.045) and worse for thin slabs, whose fixed per-launch cost the per-plane model does not know: NS over 4 1.07)
+Z_LAYER_PLANE_COST = float(os.environ.get("FDTD_SLAB_WZ", "1.4"))
 
 
 def plane_costs(nz: int, cpml_lo: int = 0, cpml_hi: int = 0, w_layer: Optional[float] = None) -> np.ndarray:

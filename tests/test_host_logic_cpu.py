@@ -59,13 +59,13 @@ def test_cost_weighted_slab_partition():
         assert max(mine) <= max(even) + 1e-12
         assert parts == sim.slab_partition(cost, world)                          # deterministic: every rank computes it alone
         if (nz, world) in ((120, 8), (128, 4)):
-            assert max(mine) / np.mean(mine) <= 1.08 and max(even) / np.mean(even) > 1.08
+            assert max(mine) / np.mean(mine) <= 1.03 and max(even) / np.mean(even) > 1.06
     with pytest.raises(ValueError):
         sim.slab_partition(np.ones(7), 4)
     # Simulation.slabs: cost-weighted by default when there are z layers, even otherwise / on request
     s = patch_sim(40, 40, 60, cpml_cells=10, nr_ts=10, nf2ff=False)
     assert s.slabs(1) == [(0, 60)] and s.slabs(4, "even") == [sim.slab_range(60, 4, r) for r in range(4)]
-    assert [nk for _, nk in s.slabs(4)] == [12, 18, 18, 12]
+    assert [nk for _, nk in s.slabs(4)] == [13, 17, 17, 13]
     assert patch_sim(40, 40, 60, boundary="PEC", nr_ts=10, nf2ff=False).slabs(4) == s.slabs(4, "even")
 
 
