@@ -51,7 +51,8 @@
 extern "C" {
 #endif
 
-#define FDTD_ABI_VERSION 2
+/* 3: fdtd_p2p_link_info, fdtd_schedule_info; FDTD_FLAG_NO_GRAPH (reserved, unused) removed; fdtd_profile.ms_update_e is per timestep */
+#define FDTD_ABI_VERSION 3
 
 enum {
   FDTD_OK = 0,
