@@ -176,3 +176,47 @@ def test_fixed_scene_end_to_end_with_oracle_engine(oracle_lib, tmp_path):
     assert r.stats["cells"] > 1e5 and r.stats["steps"] == 9000
     import os
     assert os.path.isfile(os.path.join(r.sim_path, "fdtd_hip_run.json"))
+
+
+def test_backward_flag_set_covers_every_block_an_e_block_reads():
+    """Several timesteps per launch: an E block of timestep s + 1 waits for the H flags of `wf_wait_back`'s block set
+    (csrc/kernel_common.hpp).  Brute force over tilings — rows shorter and longer than a block, short last strips, one-row
+    strips: every thread whose I values a block's threads read (own cell group, the row below, the group to the left)
+    lies in a block of that set.  (The plane below is the same block index, trivially.)  The arithmetic below restates the
+    device code's; the geometry it is checked against is enumerated cell by cell."""
+    B = 256
+    for P4, ny, tys in ((14, 52, 13), (75, 300, 17), (50, 200, 40), (257, 9, 4), (600, 12, 5), (16, 9, 9), (100, 400, 40), (9, 60, 1)):
+        nstrips = (ny + tys - 1) // tys
+        nbs = (min(tys, ny) * P4 + B - 1) // B
+        hop = 1 + P4 // B
+        for strip in range(nstrips):
+            rows = min(tys, ny - strip * tys)
+            T = rows * P4
+            for pb in range(nbs):
+                lo, hi = pb * B, min((pb + 1) * B, T)
+                if lo >= T:
+                    continue
+                # what the device waits for: (strip delta, block) pairs
+                first = pb * B - P4 - 1
+                dev = set()
+                for t in range(hop + 1):
+                    if pb - t >= 0 and (pb - t + 1) * B - 1 >= first:
+                        dev.add((0, pb - t))
+                Tp = tys * P4
+                lastb = (Tp - 1) // B
+                for q in range(hop + 1):
+                    if first < 0 and strip > 0 and lastb - q >= 0 and min((lastb - q + 1) * B, Tp) - 1 >= Tp + first:
+                        dev.add((-1, lastb - q))
+                # what the block's threads read, thread by thread
+                need = set()
+                for t in range(lo, hi):
+                    jj, c = divmod(t, P4)
+                    need.add((0, t // B))                                   # own cells
+                    if c > 0:
+                        need.add((0, (t - 1) // B))                         # the element left of the group: thread t - 1, same row
+                    if jj > 0:
+                        need.add((0, (t - P4) // B))                        # row below, same strip
+                    elif strip > 0:
+                        need.add((-1, (Tp - P4 + c) // B))                  # row below = last row of the previous (full) strip
+                assert need <= dev, (P4, ny, tys, strip, pb, sorted(need - dev))
+                assert len(dev) <= 2 * hop + 2                              # fits the polling lanes (one more lane: plane k - 1)
