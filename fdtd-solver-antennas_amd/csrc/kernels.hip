@@ -1014,7 +1014,8 @@ int xcd_adapt(fdtd_ctx* c) {
 // on cache-resident and HBM-resident grids alike, so the default is no cap.
 static unsigned lds_pad(int cap, unsigned static_bytes) {
   if (cap <= 0) return 0;
-  const unsigned total = (163840u / (unsigned)cap) & ~1023u;
+  // (1 KiB of slack: static_bytes is an upper estimate of what the kernel declares; static + dynamic must stay within 160 KiB)
+  const unsigned total = ((163840u - 1024u) / (unsigned)cap) & ~1023u;
   return total > static_bytes ? total - static_bytes : 0;
 }
 
@@ -1118,7 +1119,7 @@ template <int COEF, bool PML, bool P2P>
 static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s, int nsteps) {
   const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs;
   const unsigned lut_bytes = (unsigned)(c->raw_op ? 0 : (c->p.lut_n + 1) / 2) * 16u;
-  const unsigned pad = lut_bytes + lds_pad(c->occ_wf, (PML && FDTD_PSI_STAGE ? 20480u : 2560u) + lut_bytes);
+  const unsigned pad = lut_bytes + lds_pad(c->occ_wf, (PML && FDTD_PSI_STAGE ? 20480u : 4608u) + lut_bytes);
   const int down = (!P2P && c->p.sweep_rev && (step & 1)) ? 1 : 0;
   if (lag >= c->p.nk) {   // all E blocks, then all H blocks (cache-resident slabs: wf_lag_for), each half in eight cost-weighted XCD shares
     set_xcd_shares(c, 0, c->p.nk);
@@ -1130,8 +1131,19 @@ static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s, in
     if (nsteps > 1) {   // several timesteps in one launch (never a P2P slab: launch_step_wf); every timestep walks forwards
       const unsigned per = 2u * nE + (((unsigned)c->nprobe + 7u) & ~7u);
       c->p.xstamp = nullptr;
+      // Occupancy cap for SMALL grids.  With fewer blocks per half-step than the chip holds (7 x 256 = 1792), the blocks of the
+      // NEXT half-steps and timesteps become resident too and sit polling flags beside the blocks that do the work:
+      // 150x150x40 (960 blocks per half-step) 25.6 us per timestep with 7 blocks per CU, 18.3 with 4; 200x200x40 (1600) 24.8 ->
+      // 20.9 with 6; 100x100x40 (480) 19.1 -> 13.8 with 2; from 1920 blocks on the cap costs
+      // (profiles/r03/occupancy_cap_sweep_multi_timestep_launches.txt).  Resident slots ~ the blocks of one half-step, rounded up:
+      unsigned pad_m = pad;
+      if (c->occ_wf <= 0) {
+        const double per_cu = (double)nbp * c->p.nk / 256.0;     // blocks of one half-step per CU
+        const int cap = per_cu >= 7.0 ? FDTD_WF_MINBLOCKS : std::min(6, (int)per_cu + 1);
+        if (cap < FDTD_WF_MINBLOCKS) pad_m = lut_bytes + lds_pad(cap, (PML && FDTD_PSI_STAGE ? 20480u : 4608u) + lut_bytes);
+      }
       if constexpr (!P2P)
-        launch_main(c, k_step<COEF, PML, false, true>, dim3(per * (unsigned)nsteps), pad, s, c->p, step, -1, c->wf_epoch - (unsigned)(nsteps - 1), nbp,
+        launch_main(c, k_step<COEF, PML, false, true>, dim3(per * (unsigned)nsteps), pad_m, s, c->p, step, -1, c->wf_epoch - (unsigned)(nsteps - 1), nbp,
                     make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), 0, 2u * nE, make_fastdiv(per));
       return;
     }
