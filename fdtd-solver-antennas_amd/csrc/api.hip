@@ -871,8 +871,7 @@ static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
     c->kev0 = c->kev1 = nullptr;
     if (r) return r;
     c->step += chunk;
-    launch_dft(c, FDTD_KIND_V, c->step - 1, s);
-    launch_dft(c, FDTD_KIND_I, c->step - 1, s);
+    launch_dft(c, -1, c->step - 1, s);       // V and I boxes of the launch's last timestep in ONE launch
     n += chunk;
     ++launches;
   }

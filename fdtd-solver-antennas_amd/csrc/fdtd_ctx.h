@@ -241,7 +241,7 @@ void launch_probes(fdtd_ctx* c, long long step, hipStream_t s);   // V- and I-pr
 int build_mur_table(fdtd_ctx* c);   // after fdtd_set_mur: face table -> device
 void launch_mur(fdtd_ctx* c, int mode, hipStream_t s);
 void launch_post(fdtd_ctx* c, int kind, long long step, bool sources, hipStream_t s);   // stand-alone sources + probes
-void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);   // running DFT or time-domain recording of the boxes
+void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);   // running DFT or time-domain recording of the boxes (kind < 0: both kinds)
 void launch_rec_dft(const float* rec, long npts, int ns, int nfreq, const double* d_tw, double* d_out, hipStream_t s);
 void launch_energy(fdtd_ctx* c, hipStream_t s);
 void choose_tiling(fdtd_ctx* c);

@@ -681,16 +681,17 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_probes(const DevParams p, const 
 // ------------------------------------------------------------------------------------------------
 // K6: running DFT over registered boxes.  blockIdx.y = box, grid-stride over its points.
 // ------------------------------------------------------------------------------------------------
+// kind < 0: the boxes of BOTH kinds in one launch (the one-launch schedules sample V and I of a timestep together)
 __global__ __launch_bounds__(FDTD_BLOCK) void k_dft(const DevParams p, const int kind, const DevBox* __restrict__ boxes,
                                                     const int nfreq, const int every, const int nsamples,
-                                                    const double* __restrict__ tw, const long long step) {
+                                                    const double* __restrict__ tw_v, const double* __restrict__ tw_i, const long long step) {
   if (step % every != 0) return;
   const long long smp = step / every;
   if (smp >= nsamples) return;
   const DevBox bx = boxes[blockIdx.y];
-  if (bx.kind != kind || bx.npts == 0) return;
-  const float* F = (kind == FDTD_KIND_V ? p.V[bx.comp] : p.I[bx.comp]);
-  const double* w = tw + smp * nfreq * 2;
+  if ((kind >= 0 && bx.kind != kind) || bx.npts == 0) return;
+  const float* F = (bx.kind == FDTD_KIND_V ? p.V[bx.comp] : p.I[bx.comp]);
+  const double* w = (bx.kind == FDTD_KIND_V ? tw_v : tw_i) + smp * nfreq * 2;
   for (long pt = (long)blockIdx.x * FDTD_BLOCK + threadIdx.x; pt < bx.npts; pt += (long)gridDim.x * FDTD_BLOCK) {
     const int ii = (int)(pt % bx.ni);
     const long r = pt / bx.ni;
@@ -711,8 +712,8 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_rec(const DevParams p, const int
   const long long smp = step / every;
   if (step % every != 0 || smp >= nsamples) return;
   const DevBox bx = boxes[blockIdx.y];
-  if (bx.kind != kind || bx.npts == 0) return;
-  const float* F = (kind == FDTD_KIND_V ? p.V[bx.comp] : p.I[bx.comp]);
+  if ((kind >= 0 && bx.kind != kind) || bx.npts == 0) return;   // kind < 0: the boxes of both kinds
+  const float* F = (bx.kind == FDTD_KIND_V ? p.V[bx.comp] : p.I[bx.comp]);
   float* dst = bx.rec + (size_t)smp * bx.npts;
   for (long pt = (long)blockIdx.x * FDTD_BLOCK + threadIdx.x; pt < bx.npts; pt += (long)gridDim.x * FDTD_BLOCK) {
     const int ii = (int)(pt % bx.ni);
@@ -1301,15 +1302,16 @@ void launch_mur(fdtd_ctx* c, int mode, hipStream_t s) {
 }
 
 void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s) {
-  if (!((c->nfreq || c->recorder) && c->nbox && (step % c->every) == 0 && c->box_maxpts[kind] > 0)) return;
-  const long pts = c->box_maxpts[kind];
+  if (!((c->nfreq || c->recorder) && c->nbox && (step % c->every) == 0)) return;
+  const long pts = kind < 0 ? std::max(c->box_maxpts[0], c->box_maxpts[1]) : c->box_maxpts[kind];
+  if (pts <= 0) return;
   unsigned gx = (unsigned)((pts + FDTD_BLOCK - 1) / FDTD_BLOCK);
   if (gx > 1024) gx = 1024;
   if (c->recorder)
     hipLaunchKernelGGL(k_rec, dim3(gx, (unsigned)c->nbox), dim3(FDTD_BLOCK), 0, s, c->p, kind, c->d_box, c->every, c->nsamples, step);
   else
     hipLaunchKernelGGL(k_dft, dim3(gx, (unsigned)c->nbox), dim3(FDTD_BLOCK), 0, s, c->p, kind, c->d_box, c->nfreq,
-                       c->every, c->nsamples, kind == FDTD_KIND_V ? c->tw_v : c->tw_i, step);
+                       c->every, c->nsamples, c->tw_v, c->tw_i, step);
 }
 
 void launch_rec_dft(const float* rec, long npts, int ns, int nfreq, const double* d_tw, double* d_out, hipStream_t s) {
