@@ -102,22 +102,6 @@ def main():
     # pre-fill lasts ~--prefill-seconds of GPU time, as a timestep count that depends on the grid size only (the same for every N)
     prefill = max(2 * max(w.grid.shape), int(args.prefill_seconds * 75e9 / w.grid.ncells))
     nts_total = (args.steps + args.warmup) * args.ts_per_step * 2 + prefill + 8
-    sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=args.cpml_cells,
-                          nr_ts=nts_total, nf2ff_freqs=[w.f0], nf2ff_mode="auto", use_classes=not args.raw_operator)
-    eng = sim.build(hip, rank=rank, world=world, device=local_rank, partition=args.partition)
-    comm = None
-    if world > 1:
-        # halo transport inside the library: P2P mailboxes (kernels push the halo planes over xGMI), else RCCL
-        # send/recv on a second stream; if neither can be set up on this node every rank falls back (together) to
-        # the host transport so that the run still produces a valid number
-        comm = importlib.import_module(PKG + ".distributed").SlabComm(transport=args.halo)
-        comm.attach(sim)
-
-    def run_steps(n):
-        if sim.external_transport is not None:
-            sim.external_transport.run_steps(eng, n)
-        else:
-            eng.run(n)
 
     def barrier():
         torch.cuda.synchronize()
@@ -125,8 +109,46 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # N > 1: the halo transport lives inside the library — P2P mailboxes (kernels push the halo planes over xGMI), else RCCL
+    # send/recv on a second stream, else host copies; SlabComm.attach falls down that ladder TOGETHER on every rank when one of
+    # them cannot set a transport up.  A transport that sets up (and passes its self-test) but fails once timesteps depend on it
+    # — every halo wait is bounded and ends in an error, never in a hang — is caught here the same way: the first pre-fill
+    # timesteps are the probe, and on an error on any rank all ranks rebuild their slab and take the next transport, so that the
+    # run still produces a valid number (and says in `multi_gpu.transports_failed` what happened).
+    failed, comm = [], None
+    while True:
+        sim = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=args.cpml_cells,
+                              nr_ts=nts_total, nf2ff_freqs=[w.f0], nf2ff_mode="auto", use_classes=not args.raw_operator)
+        eng = sim.build(hip, rank=rank, world=world, device=local_rank, partition=args.partition)
+        if world == 1:
+            break
+        comm = importlib.import_module(PKG + ".distributed").SlabComm(transport=args.halo, skip=[f["transport"] for f in failed])
+        comm.attach(sim)
+        ok, why = True, ""
+        if sim.external_transport is None:
+            try:
+                eng.run(min(64, prefill))
+            except capi.FdtdError as exc:
+                ok, why = False, str(exc)
+        if comm._all_agree(ok):
+            break
+        if args.halo != "auto":
+            raise RuntimeError(f"halo transport {comm.transport_used} failed at run time on some rank" + (f": {why}" if why else ""))
+        failed.append({"transport": comm.transport_used, "error_on_this_rank": why or None})
+        if rank == 0:
+            print(f"[bench] halo transport {comm.transport_used} failed at run time; rebuilding with the next one", file=sys.stderr, flush=True)
+        comm.barrier()                        # nobody frees a mailbox a neighbour may still write into
+        del eng
+        sim.engine = None
+
+    def run_steps(n):
+        if sim.external_transport is not None:
+            sim.external_transport.run_steps(eng, n)
+        else:
+            eng.run(n)
+
     tps = args.ts_per_step
-    done = 0
+    done = int(eng.step)
     while done < prefill:                  # in calls of at most 2000 timesteps (a decomposed grid enqueues two launches per timestep)
         n = min(2000, prefill - done)
         run_steps(n)
@@ -187,7 +209,7 @@ def main():
             mine["ms_p2p_selftest"] = round(comm.ms_selftest, 3)
         dist.all_gather_object(rec, mine)
         t_rank = [r["us_per_timestep"] for r in rec]
-        coupling = {"ranks_seen": int(round(float(seen[0]))), "transport_used": comm.transport_used,
+        coupling = {"ranks_seen": int(round(float(seen[0]))), "transport_used": comm.transport_used, "transports_failed": failed,
                     "partition": args.partition, "z_layer_plane_cost": simm.Z_LAYER_PLANE_COST,
                     "rccl_nranks": rec[0]["rccl_nranks"], "per_rank": rec,
                     "rank_time_max_over_mean": round(max(t_rank) / (sum(t_rank) / len(t_rank)), 4),

@@ -187,6 +187,7 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   if (const char* v = getenv("FDTD_WF_LAG")) c->wf_lag = std::max(0, std::min(4096, atoi(v)));
   if (const char* v = getenv("FDTD_WF_MULTI")) c->wf_multi = std::max(1, std::min(4096, atoi(v)));   // timesteps per launch at most (1: one launch per timestep)
   if (const char* v = getenv("FDTD_OCC_H")) c->occ_h = std::max(0, std::min(16, atoi(v)));
+  if (const char* v = getenv("FDTD_P2P_FAULT_STEP")) c->p2p_fault_step = atoll(v);   // test hook: see fdtd_run
   if (const char* v = getenv("FDTD_WF_FAULT_STEP")) c->wf_fault_step = atoll(v);   // test hook: the H blocks of that step wait for flags nobody sets (bounded wait -> error word)
   if (const char* v = getenv("FDTD_XCD_BALANCE")) c->xcd_balance = atoi(v) != 0;        // experiments: 0 = XCD shares of equal length
   if (const char* v = getenv("FDTD_XCD_ADAPT")) c->xcd_adapt = atoi(v) != 0;            // 0 = the cost model's cuts, never the measured ones
@@ -965,7 +966,11 @@ int fdtd_run(fdtd_ctx* c, int nsteps) {
   int r = check_ready(c);
   if (r) return r;
   HIPCK(c, hipSetDevice(c->d.device));
+  const bool p2p_fault = c->p.p2p && c->p2p_fault_step >= c->step && c->p2p_fault_step < c->step + nsteps;
+  const unsigned long long p2p_limit = c->p.p2p_limit;
+  if (p2p_fault) { c->p.p2p_tag_bias = 0x40000000u; c->p.p2p_limit = 2000ull; }   // test hook: tags nobody sends, 20 us
   r = step_loop(c, nsteps, nullptr);
+  if (p2p_fault) { c->p.p2p_tag_bias = 0u; c->p.p2p_limit = p2p_limit; c->p2p_fault_step = -1; }
   if (r) return r;
   HIPCK(c, hipStreamSynchronize(c->stream));
   HIPCK(c, hipStreamSynchronize(c->comm_stream));

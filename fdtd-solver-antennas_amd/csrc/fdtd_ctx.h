@@ -103,6 +103,7 @@ struct DevParams {
   float* mb_out_E; float* mb_out_H;   // lower neighbour's mb_in_E / upper neighbour's mb_in_H
   int* p2p_err;              // set when a halo wait timed out
   unsigned long long p2p_limit;   // wall-clock ticks a halo wait may last (10 s)
+  unsigned p2p_tag_bias;     // added to the tag the halo waits expect: 0, except under the fault-injection test hook ($FDTD_P2P_FAULT_STEP)
   // one launch per timestep (k_step): per-block completion flags of the E blocks [nk][nstrips][nbs], error word, wait limit
   unsigned* wf_flags; int* wf_err; unsigned long long wf_limit;
   unsigned wf_wait_bias;     // added to the flag value the H blocks wait for: 0, except under the fault-injection test hook
@@ -148,6 +149,7 @@ struct fdtd_ctx {
   int wf_lag = 0;                // planes the E sweep runs ahead (0: auto); $FDTD_WF_LAG
   unsigned* wf_flags = nullptr; size_t wf_nflags = 0; int* wf_err = nullptr;
   unsigned wf_epoch = 0;         // flag value of the last wavefront launch
+  long long p2p_fault_step = -1; // test hook ($FDTD_P2P_FAULT_STEP): a run that covers that step waits for halo tags nobody sends (bounded wait -> error)
   long long wf_fault_step = -1;  // test hook ($FDTD_WF_FAULT_STEP): at that step the H blocks wait for a flag value nobody publishes
   unsigned* wf_flagsH = nullptr; int* wf_prb_sp = nullptr; int* wf_prb_blk = nullptr; int2* wf_prb_rng = nullptr;
   int* wf_prbV_sp = nullptr; unsigned* wf_prb_done = nullptr;

@@ -173,7 +173,7 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
     psi_stage_issue<MULTI>(p, p.psiE, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
   if (dep_in) {   // H halo of step-1 (tag = step + 1; for step 0 the neighbour's INITIAL top plane, pushed by k_p2p_prime); slot of the parity of the step that produced it
     const float* mb = p.mb_in_H + (size_t)((step + 1) & 1) * 2 * mb_slot_words(p);
-    mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u, ix_km, iy_km, p.p2p_err, p.p2p_limit);
+    mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u + p.p2p_tag_bias, ix_km, iy_km, p.p2p_err, p.p2p_limit);
   }
 
   // component x: d1 along y (of Iz), d2 along z (of Iy); y: d1 along z (Ix), d2 along x (Iz);
@@ -394,7 +394,7 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
   }
   if (dep_in) {   // E halo of this step (tag = step + 1)
     const float* mb = p.mb_in_E + (size_t)(step & 1) * 2 * mb_slot_words(p);
-    mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u, vx_kp, vy_kp, p.p2p_err, p.p2p_limit);
+    mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u + p.p2p_tag_bias, vx_kp, vy_kp, p.p2p_err, p.p2p_limit);
   }
 
   float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);

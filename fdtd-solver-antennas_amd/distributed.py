@@ -26,7 +26,7 @@ from . import _capi
 
 
 class SlabComm:
-    def __init__(self, transport: str = "auto"):
+    def __init__(self, transport: str = "auto", skip=()):
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (one process per GPU)")
@@ -34,6 +34,7 @@ class SlabComm:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.backend = dist.get_backend()
         self.transport = transport
+        self.skip = set(skip)        # "auto" only: transports not to try (a caller that has seen one fail at run time)
         self.sim = None
         self.transport_used = None
         self.rccl_error = None
@@ -77,7 +78,7 @@ class SlabComm:
             return
         on_gpu = eng.backend.startswith("hip")
         want = self.transport
-        if want in ("p2p", "auto"):
+        if want == "p2p" or (want == "auto" and "p2p" not in self.skip):
             eligible = on_gpu and not sim.mur_enable.any() and eng.nk >= 2
             if self._all_agree(eligible):
                 ok, blobs = True, [None] * self.world
@@ -112,7 +113,7 @@ class SlabComm:
                     print(f"[fdtd-hip rank {self.rank}] p2p halo transport not usable: {self.p2p_error}", file=sys.stderr, flush=True)
             if want == "p2p":
                 raise RuntimeError(f"p2p halo transport unavailable: {self.p2p_error or 'not eligible (Mur faces, CPU engine or 1-plane slab)'}")
-        if want in ("rccl", "auto") and on_gpu:
+        if (want == "rccl" or (want == "auto" and "rccl" not in self.skip)) and on_gpu:
             uid = [_capi.comm_unique_id(eng.lib) if self.rank == 0 else None]
             self.dist.broadcast_object_list(uid, src=0)
             ok = True

@@ -56,7 +56,7 @@ def test_bench_under_torchrun_couples_the_ranks(single, nranks, halo):
     assert out["config"]["fields_finite"] and out["config"]["timesteps_total"] == single["config"]["timesteps_total"]
     mg = out["multi_gpu"]
     assert mg["ranks_seen"] == nranks and len(mg["per_rank"]) == nranks
-    assert mg["transport_used"] == ("p2p" if halo in ("p2p", "auto") else "host")
+    assert mg["transport_used"] == ("p2p" if halo in ("p2p", "auto") else "host") and mg["transports_failed"] == []
     assert f"z-slab x{nranks}" in out["config"]["parallelism"] and mg["transport_used"] in out["config"]["parallelism"]
     assert sum(r["slab_planes"] for r in mg["per_rank"]) == 40
     # the record describes itself: partition, per-rank planes / z-layer planes / time / schedule, and (p2p) what the runtime knows
@@ -79,6 +79,26 @@ def test_bench_under_torchrun_couples_the_ranks(single, nranks, halo):
     # the decomposed run IS the single-slab run: same port voltage series (float64 sums in another order)
     assert abs(out["config"]["port_u_l2"] - single["config"]["port_u_l2"]) <= 1e-9 * single["config"]["port_u_l2"]
     assert single["config"]["port_u_l2"] > 0
+
+
+def test_bench_takes_the_next_transport_when_one_fails_at_run_time(single):
+    """The P2P transport sets up and passes its self-test, then its halo waits time out once timesteps depend on them (test hook:
+    the waits of a run covering $FDTD_P2P_FAULT_STEP expect tags nobody sends; 20 us bound).  Every rank sees the error, all of them
+    rebuild their slab and go down the ladder together — RCCL refuses two ranks on one device, so this box ends on the host
+    transport — and the line is the valid result of the SAME run: same timestep count, same port series, the failure on record."""
+    out = _bench(2, ["--halo", "auto"], env_extra={"FDTD_P2P_FAULT_STEP": "10"})
+    mg = out["multi_gpu"]
+    assert [f["transport"] for f in mg["transports_failed"]] == ["p2p"] and "halo wait timed out" in mg["transports_failed"][0]["error_on_this_rank"]
+    assert mg["transport_used"] == "host" and mg["ranks_seen"] == 2 and mg["all_slabs_excited"]
+    assert out["config"]["fields_finite"] and out["config"]["timesteps_total"] == single["config"]["timesteps_total"]
+    assert abs(out["config"]["port_u_l2"] - single["config"]["port_u_l2"]) <= 1e-9 * single["config"]["port_u_l2"]
+    # ... and an explicitly requested transport is not replaced behind the caller's back
+    env = dict(os.environ)
+    env.update({"FDTD_BENCH_FORCE_DEVICE": "0", "FDTD_BENCH_DIST_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1", "FDTD_P2P_FAULT_STEP": "10"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ARGS + ["--halo", "p2p"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "failed at run time" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_bench_default_nccl_bootstrap_at_world_one():
