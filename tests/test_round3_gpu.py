@@ -303,3 +303,20 @@ def test_cpml_terminating_a_dielectric_on_the_gpu(hip_lib, half):
     big = kat._plate_line(hip_lib, n + 2 * off, n + 2 * off, "PEC", steps, (32 + off, 32 + off), (40 + off, 27 + off), 4.3, half)
     err = np.max(np.abs(small - big)) / np.max(np.abs(big))
     assert 20 * np.log10(err) < -60.0, f"reflection {20 * np.log10(err):.1f} dB"
+
+
+def test_randomised_cases_equal_the_oracle(hip_lib, oracle_lib):
+    """A fixed-seed batch of tests/fuzz_parity.py: 48 drawn combinations of grid shape, boundary per face, layer thickness, operator
+    form, schedule, tiling, timesteps per launch, NF2FF mode and run-call lengths — fields bit for bit, port series, energy and NF2FF
+    face spectra against the oracle.  (580 + 150 further cases of other seeds: profiles/r03/randomised_parity.txt.)"""
+    import fuzz_parity
+    lines = []
+    failed = fuzz_parity.run_batch(48, 7, hip_lib, oracle_lib, log=lines.append)
+    ran = [l for l in lines if ": ok " in l or ": FAIL" in l]
+    assert len(ran) >= 40, "\n".join(lines)
+    assert not failed, "\n".join(l for l in lines if "FAIL" in l)
+    assert any("ts/launch 64" in l for l in ran) and any("launches/ts 3" in l for l in ran) and any("launches/ts 2" in l for l in ran)
+    # ... and decomposed runs: 2 ... 6 P2P slabs of drawn partition and per-slab schedule in this process against ONE slab on the oracle
+    lines = []
+    failed = fuzz_parity.run_batch(16, 11, hip_lib, oracle_lib, log=lines.append, slabs=True)
+    assert len([l for l in lines if ": ok " in l]) >= 12 and not failed, "\n".join(lines)
