@@ -111,6 +111,8 @@ __global__ __launch_bounds__(256) void k_fused(const Arr a, const int m, const i
 template <bool SC>
 __global__ __launch_bounds__(256) void k_fused_flags(const Arr a, const int m, const int nz, const size_t plane4, const int lag,
                                                      unsigned* flag, const unsigned target, int* err) {
+  extern __shared__ float ballast[];   // (occupancy ballast of the EH_PROBE_OCC sweep; touched so that it is not optimised away)
+  if (threadIdx.x == 1023) ballast[0] = 0.f;
   const unsigned b = blockIdx.x, x = b & 7u, pos = b >> 3;
   const unsigned grp = pos / (unsigned)(2 * m), w = pos - grp * (unsigned)(2 * m);
   const bool isH = w >= (unsigned)m;
@@ -246,6 +248,27 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         char tag[64]; snprintf(tag, sizeof tag, "wavefront T=%d lag %2d no deps + sc1", T, lag);
         report(tag, ms * reps / (float)(nl * T));
+      }
+    }
+    // round 3, second question: the block-flag variants again with FEWER workgroups per CU (dynamic LDS as ballast) — a block of the
+    // full-occupancy launch lives ~10 us = ~9 plane groups of dispatch, so an H block that follows E by fewer groups waits; with 1 ... 4
+    // workgroups per CU a block lives shorter, a small lag may do, and at a small lag H finds E's output in the L2 of its XCD
+    if (getenv("EH_PROBE_OCC")) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_flags<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_flags<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      for (int sc : {0, 1}) for (int occ : {1, 2, 3, 4, 6}) for (int lag : {1, 2, 3, 4, 6, 8}) {
+        const unsigned grid = 8u * 2u * m * (g.nz + lag);
+        const size_t lds = (size_t)(160 * 1024 / occ - 1024) & ~(size_t)1023;
+        for (int it = -3; it < reps; ++it) {
+          if (it == 0) hipEventRecord(e0);
+          ++launches;
+          if (sc) hipLaunchKernelGGL((k_fused_flags<true>), dim3(grid), dim3(256), lds, 0, a, m, g.nz, plane4, lag, flag, launches, err);
+          else hipLaunchKernelGGL((k_fused_flags<false>), dim3(grid), dim3(256), lds, 0, a, m, g.nz, plane4, lag, flag, launches, err);
+        }
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        char tag[64]; snprintf(tag, sizeof tag, "flags %s occ %d lag %2d", sc ? "sc1  " : "plain", occ, lag);
+        report(tag, ms);
       }
     }
     for (int c = 0; c < 3; ++c) { hipFree(a.V[c]); hipFree(a.I[c]); }
