@@ -366,6 +366,24 @@ __device__ __forceinline__ void cpml_row4(float4& d, float* base, const unsigned
 // are issued early into LDS instead (global_load_lds_dwordx4: no register destination), right behind the field loads,
 // and read back from LDS when the differences are ready.  Each wave owns PSI_SLOTS KiB of staging, lane-linear per slot
 // (the LDS destination of an LDS-DMA load is wave-uniform base + lane * 16): slots 0,1 the x-directed pair, 2,3 the z pair.
+// The x-neighbour scalars of the stencils — I(i0 - 1) for update_E, V(i0 + 4) for update_H — are the last / first element of the float4 the
+// NEIGHBOUR LANE has just loaded (threads are linear in memory within a strip-plane, rows included): one DPP wave shift instead of a second
+// vector-memory instruction whose 64 lanes touch sixteen 64-byte segments for 4 bytes each.  Only the lane at the wave's edge (and, for H, the
+// last thread of a strip-plane, whose neighbour thread does not exist) still loads from memory.  0: the scalar loads of rounds 1-2.
+#ifndef FDTD_LANE_SHIFT
+#define FDTD_LANE_SHIFT 1
+#endif
+// ... where the kernel has the register it costs: the launches of several timesteps (MULTI) keep their 7 waves per SIMD; the one-launch kernels of
+// the grids beyond the Infinity Cache sit exactly on 72 VGPRs and would spill (12-60 bytes per lane), several two-launch kernels would drop from 7
+// to 6 waves per SIMD (tools/kernel_resources.py)
+#define LANE_SHIFT_FITS(WF, MULTI) (MULTI)
+__device__ __forceinline__ float lane_prev(const float v) {   // lane l <- lane l - 1 (wave_shr:1); lane 0 gets 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_next(const float v) {   // lane l <- lane l + 1 (wave_shl:1); lane 63 gets 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
 #ifndef FDTD_PSI_STAGE
 #define FDTD_PSI_STAGE 1
 #endif

@@ -125,6 +125,7 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
   int j = 0, i0 = 0;
   const bool valid = decode_thread(p, strip, pb, j, i0);
   const int off = k * p.plane + (valid ? j * p.P + i0 : 0);
+  constexpr bool LS = FDTD_LANE_SHIFT && LANE_SHIFT_FITS(WF, MULTI);
   // ONE per-lane offset for all thirteen loads: the neighbour displacements (k-1, j-1, i-1) go into the SCALAR base
   // pointers (SGPRs are plentiful, VGPRs decide the occupancy); bases start one plane below plane 0 (the ghost plane), so
   // that the offset stays unsigned whatever the displacement
@@ -139,7 +140,10 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
     ix = ldo4(I0, uo); iy = ldo4(I1, uo); iz = ldo4(I2, uo);
     iz_jm = ldo4(I2 - p.P, uo); ix_jm = ldo4(I0 - p.P, uo);
     if (!dep_in) { iy_km = ldo4(I1 - p.plane, uo); ix_km = ldo4(I0 - p.plane, uo); }
-    iz_im = ldo1(I2 - 1, uo); iy_im = ldo1(I1 - 1, uo);
+    {   // (FDTD_LANE_SHIFT: only lane 0 needs these from memory — the others take lane 0's address, one segment for the whole wave, and lane_prev below)
+      const unsigned ue = (!LS || (threadIdx.x & 63u) == 0u) ? uo : (unsigned)__builtin_amdgcn_readfirstlane((int)uo);
+      iz_im = ldo1(I2 - 1, ue); iy_im = ldo1(I1 - 1, ue);
+    }
     vx = ldo4(p.V[0] - p.plane, uo); vy = ldo4(p.V[1] - p.plane, uo); vz = ldo4(p.V[2] - p.plane, uo);
   } else {
     // the H blocks of the previous timestep that wrote what this block reads have published (and the probe blocks that sample
@@ -155,7 +159,10 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
     ix = ldb4_dev(r0, bo, d0); iy = ldb4_dev(r1, bo, d0); iz = ldb4_dev(r2, bo, d0);
     iz_jm = ldb4_dev(r2, bo, dj); ix_jm = ldb4_dev(r0, bo, dj);
     iy_km = ldb4_dev(r1, bo, dk); ix_km = ldb4_dev(r0, bo, dk);
-    iz_im = ldb1_dev(r2, bo, di); iy_im = ldb1_dev(r1, bo, di);
+    {
+      const unsigned be = (!LS || (threadIdx.x & 63u) == 0u) ? bo : (unsigned)__builtin_amdgcn_readfirstlane((int)bo);
+      iz_im = ldb1_dev(r2, be, di); iy_im = ldb1_dev(r1, be, di);
+    }
     vx = ldb4_dev(dev_buf(p.V[0]), bo, 0u); vy = ldb4_dev(dev_buf(p.V[1]), bo, 0u); vz = ldb4_dev(dev_buf(p.V[2]), bo, 0u);
   }
   MurVals mv;
@@ -178,6 +185,10 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
 
   // component x: d1 along y (of Iz), d2 along z (of Iy); y: d1 along z (Ix), d2 along x (Iz);
   // z: d1 along x (Iy), d2 along y (Ix)
+  if (LS) {   // every lane active here (out-of-range threads leave after the barrier below)
+    const float zp = lane_prev(iz.w), yp = lane_prev(iy.w);
+    if ((threadIdx.x & 63u) != 0u) { iz_im = zp; iy_im = yp; }
+  }
   float4 dx1 = sub4(iz, iz_jm), dx2 = sub4(iy, iy_km);
   float4 dy1 = sub4(ix, ix_km);
   float4 dy2 = make_float4(iz.x - iz_im, iz.y - iz.x, iz.z - iz.y, iz.w - iz.z);
@@ -357,11 +368,18 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
   float4 vx, vy, vz, vz_jp, vx_jp, ix, iy, iz;
   float4 vy_kp = make_float4(0.f, 0.f, 0.f, 0.f), vx_kp = vy_kp;
   float vz_ip, vy_ip;
+  // (lane shift) the thread whose right-hand neighbour thread is in another wave, or does not exist (end of the strip-plane), loads
+  constexpr bool LS = FDTD_LANE_SHIFT && LANE_SHIFT_FITS(WF, MULTI);
+  const bool ip_load = !LS || (threadIdx.x & 63u) == 63u ||
+                       pb * FDTD_BLOCK + (int)threadIdx.x + 1 >= min(p.tys, p.ny - strip * p.tys) * p.P4;
   if (!WF) {
     vx = ldo4(p.V[0], uo); vy = ldo4(p.V[1], uo); vz = ldo4(p.V[2], uo);
     vz_jp = ldo4(p.V[2] + p.P, uo); vx_jp = ldo4(p.V[0] + p.P, uo);   // neighbour displacements in the scalar bases: one offset VGPR
     if (!dep_in) { vy_kp = ldo4(p.V[1] + p.plane, uo); vx_kp = ldo4(p.V[0] + p.plane, uo); }
-    vz_ip = ldo1(p.V[2] + 4, uo); vy_ip = ldo1(p.V[1] + 4, uo);
+    {
+      const unsigned ue = ip_load ? uo : (unsigned)__builtin_amdgcn_readfirstlane((int)uo);
+      vz_ip = ldo1(p.V[2] + 4, ue); vy_ip = ldo1(p.V[1] + 4, ue);
+    }
     ix = ldo4(p.I[0], uo); iy = ldo4(p.I[1], uo); iz = ldo4(p.I[2], uo);
     if (staged)
       psi_stage_issue(p, p.psiH, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
@@ -390,13 +408,20 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
     vx = ldb4_dev(b0, bo, 0u); vy = ldb4_dev(b1, bo, 0u); vz = ldb4_dev(b2, bo, 0u);
     vz_jp = ldb4_dev(b2, bo, (unsigned)p.P << 2); vx_jp = ldb4_dev(b0, bo, (unsigned)p.P << 2);
     if (!dep_in) { vy_kp = ldb4_dev(b1, bo, (unsigned)p.plane << 2); vx_kp = ldb4_dev(b0, bo, (unsigned)p.plane << 2); }
-    vz_ip = ldb1_dev(b2, bo, 16u); vy_ip = ldb1_dev(b1, bo, 16u);
+    {
+      const unsigned be = ip_load ? bo : (unsigned)__builtin_amdgcn_readfirstlane((int)bo);
+      vz_ip = ldb1_dev(b2, be, 16u); vy_ip = ldb1_dev(b1, be, 16u);
+    }
   }
   if (dep_in) {   // E halo of this step (tag = step + 1)
     const float* mb = p.mb_in_E + (size_t)(step & 1) * 2 * mb_slot_words(p);
     mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u + p.p2p_tag_bias, vx_kp, vy_kp, p.p2p_err, p.p2p_limit);
   }
 
+  if (LS) {
+    const float zn = lane_next(vz.x), yn = lane_next(vy.x);
+    if (!ip_load) { vz_ip = zn; vy_ip = yn; }
+  }
   float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);
   float4 dy1 = sub4(vx, vx_kp);
   float4 dy2 = make_float4(vz.x - vz.y, vz.y - vz.z, vz.z - vz.w, vz.w - vz_ip);
