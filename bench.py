@@ -126,6 +126,7 @@ def main():
         comm.attach(sim)
         ok, why = True, ""
         if sim.external_transport is None:
+            comm.barrier()                    # every rank starts its first launch now: a halo wait is bounded (10 s), set-up times differ
             try:
                 eng.run(min(64, prefill))
             except capi.FdtdError as exc:
