@@ -72,6 +72,7 @@ class SlabComm:
         "host" fdtd_half_step + torch.distributed send/recv (any engine, used by the gloo CPU tests).
         "auto" = p2p, then rccl, then host, falling back TOGETHER when a rank cannot set one up."""
         self.sim = sim
+        sim.comm = self              # Simulation.run: which transport, and the ladder when it fails in the first timesteps
         eng = sim.engine
         if self.world == 1:
             sim.external_transport = None

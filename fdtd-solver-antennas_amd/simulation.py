@@ -124,6 +124,7 @@ class RunStats:
     energy_db: float = 0.0
     stopped_by_energy: bool = False
     schedule_fallback: Optional[str] = None   # set when the run was repeated under the two-launch schedule (see Simulation.run)
+    transports_failed: tuple = ()             # decomposed run: halo transports that set up but failed in the first timesteps (see Simulation.run)
 
 
 class Simulation:
@@ -276,10 +277,32 @@ class Simulation:
         t0 = time.perf_counter()
         done = e.step
         fresh = done == 0          # stepping from the state build() left: a repeat from scratch reproduces it
+        comm = getattr(self, "comm", None)      # distributed.SlabComm.attach leaves itself here
         while done < total:
             n = min(check_every, total - done)
             if self.external_transport is not None:
                 self.external_transport.run_steps(e, n)
+            elif self.world > 1 and fresh and done == 0 and comm is not None and comm.transport == "auto":
+                # Decomposed run, first timesteps: the probe of the halo transport the ranks agreed on.  One that set up (and passed
+                # its self-test) but errors once timesteps depend on it — every halo wait is bounded — sends ALL ranks to the next
+                # transport (p2p -> rccl -> host): new contexts, from the initial state.
+                ok, why = True, ""
+                try:
+                    e.run(n)
+                except _capi.FdtdError as exc:
+                    ok, why = False, str(exc)
+                if not comm._all_agree(ok):
+                    log(f"[fdtd-hip rank {self.rank}] halo transport {comm.transport_used} failed at run time"
+                        + (f" ({why})" if why else "") + " — every rank takes the next one")
+                    stats.transports_failed += (comm.transport_used,)
+                    comm.skip.add(comm.transport_used)
+                    comm.barrier()                  # nobody frees a mailbox a neighbour may still write into
+                    e.close()
+                    e = self.build(self.lib, rank=self.rank, world=self.world, device=self.device, partition=self.partition,
+                                   flags=self._build_flags)
+                    comm.attach(self)
+                    emax = 0.0
+                    continue
             else:
                 try:
                     e.run(n)
