@@ -308,7 +308,7 @@ def test_cpml_terminating_a_dielectric_on_the_gpu(hip_lib, half):
 def test_randomised_cases_equal_the_oracle(hip_lib, oracle_lib):
     """A fixed-seed batch of tests/fuzz_parity.py: 48 drawn combinations of grid shape, boundary per face, layer thickness, operator
     form, schedule, tiling, timesteps per launch, NF2FF mode and run-call lengths — fields bit for bit, port series, energy and NF2FF
-    face spectra against the oracle.  (580 + 150 further cases of other seeds: profiles/r03/randomised_parity.txt.)"""
+    face spectra against the oracle.  (1060 + 350 further cases of other seeds: profiles/r03/randomised_parity.txt.)"""
     import fuzz_parity
     lines = []
     failed = fuzz_parity.run_batch(48, 7, hip_lib, oracle_lib, log=lines.append)
