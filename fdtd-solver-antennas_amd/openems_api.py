@@ -448,7 +448,10 @@ class openEMS:
                     json.dump({"grid": [nx, ny, nz], "cells": grid.ncells, "dt": self.sim.dt,
                                "steps": self.stats.steps, "seconds": self.stats.seconds,
                                "mcells_per_s": self.stats.mcells_per_s, "energy_db": float(self.stats.energy_db),
-                               "operator": self.sim.operator_form, "n_gpus": self._world}, fh)
+                               "operator": self.sim.operator_form, "n_gpus": self._world,
+                               "halo_transport": getattr(self._comm, "transport_used", None),
+                               "halo_transports_failed": list(self.stats.transports_failed),
+                               "schedule_fallback": self.stats.schedule_fallback}, fh)
                 # the port series as upstream's probe files (text): only on request — formatting them takes 0.03 s of a
                 # 0.34 s call on the reference's default scene, and CalcPort reads the arrays, not the files
                 if int(verbose or 0) > 0 or os.environ.get("FDTD_WRITE_PORT_FILES"):
