@@ -74,7 +74,10 @@ def patch_workload(name: str = "NS", *, nx=None, ny=None, nz=None, f0=None, eps_
     x = np.linspace(-box_xy / 2, box_xy / 2, nx)
     y = np.linspace(-box_xy / 2, box_xy / 2, ny)
     dxy = float(x[1] - x[0])
-    z = graded_z_lines(nz, h, 4, dz_max=max(dxy, h / 4))
+    # (BASELINE config 2 has 40 planes for two 10-cell CPML layers: with a third of the spare planes below the ground plane, as on the other
+    # grids, it would sit on plane 12 — the very plane of the NF2FF box's lower face (layer + 2) — and the far field would be that of a
+    # surface cut along a PEC sheet (D = 14.6 dBi); 14 planes below put the face two cells under the ground plane)
+    z = graded_z_lines(nz, h, 4, dz_max=max(dxy, h / 4), frac_below=0.41 if name == "C2" else 1.0 / 3.0)
     grid = RectGrid(x, y, z)
     L, W, _ = design_patch_for_frequency(f0, eps_r, h)
     u = 1e-3
