@@ -220,3 +220,23 @@ def test_backward_flag_set_covers_every_block_an_e_block_reads():
                         need.add((-1, (Tp - P4 + c) // B))                  # row below = last row of the previous (full) strip
                 assert need <= dev, (P4, ny, tys, strip, pb, sorted(need - dev))
                 assert len(dev) <= 2 * hop + 2                              # fits the polling lanes (one more lane: plane k - 1)
+
+
+def test_nf2ff_box_on_a_metal_sheet_is_flagged():
+    """A Huygens face that lies ON the ground plane (BASELINE config 2's 40 planes with a third of the spare ones below the ground plane:
+    plane 12 = layer + 2) gives a far field that is not the antenna's (D read 14.6 dBi for a 6.2 dBi patch): Simulation warns and keeps
+    the text; the shipped C2 workload puts the ground plane on plane 14 and is clean, like the other BASELINE grids."""
+    import warnings
+    wl, sc, simm = pkg("workloads"), pkg("scene"), pkg("simulation")
+
+    def build(w):
+        vox = sc.voxelize(w.scene, w.grid)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            s = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=10, nr_ts=10, nf2ff_freqs=[w.f0])
+        return s, [c for c in caught if issubclass(c.category, RuntimeWarning)]
+    s, caught = build(wl.patch_workload("third-below", nx=100, ny=100, nz=40))
+    assert s.nf2ff_warning and "z-min face (node plane 12)" in s.nf2ff_warning and len(caught) == 1
+    for name in ("C2", "NS"):
+        s, caught = build(wl.baseline_workload(name))
+        assert s.nf2ff_warning is None and not caught
