@@ -654,8 +654,9 @@ def run_prepared_hip(prepared: FDTDPrepared, *, frequency_hz: float, verbose: in
         st = fdtd.stats
         out.stats = {"steps": st.steps, "seconds": st.seconds, "mcells_per_s": st.mcells_per_s,
                      "energy_db": float(st.energy_db), "cells": fdtd.sim.grid.ncells,
-                     "grid": list(fdtd.sim.grid.shape), "schedule_fallback": st.schedule_fallback,
-                     "halo_transports_failed": list(st.transports_failed), "nf2ff_warning": fdtd.sim.nf2ff_warning}
+                     "grid": list(fdtd.sim.grid.shape), "schedule_fallback": getattr(st, "schedule_fallback", None),
+                     "halo_transports_failed": list(getattr(st, "transports_failed", ())),
+                     "nf2ff_warning": getattr(fdtd.sim, "nf2ff_warning", None)}
         if verbose:
             print(f"[fdtd-hip] done: {st.steps} steps, {st.mcells_per_s:.0f} MC/s, Dmax {10 * np.log10(Dmax):.2f} dBi", flush=True)
         return out
