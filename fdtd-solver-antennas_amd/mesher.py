@@ -4,8 +4,9 @@ Restates what the reference asks of the external toolkit through
 ``FDTD.AddEdges2Grid(dirs, properties, metal_edge_res)`` and ``mesh.SmoothMeshLines('all', res, 1.4)``
 (antenna_sim/solver_fdtd_openems_fixed.py:193,210,217): [EXT] openEMS automesh / CSXCAD
 SmoothMeshLines.  Their source is not available here, so line positions are NOT pinned against
-them; the invariants are (tests/test_host_logic_cpu.py::test_mesher_*): every hint line is kept, no cell exceeds
-max_res, neighbouring cells differ by at most `ratio` wherever the hints allow it.
+them; the invariants are (tests/test_host_logic_cpu.py::test_mesher_*): every hint line is kept (pairs closer than max_res / 100
+become one line at their mean: merge_close_lines), no cell exceeds max_res, neighbouring cells differ by at most `ratio` wherever
+the hints allow it.
 """
 from __future__ import annotations
 
@@ -68,12 +69,40 @@ def _graded_fill(a: float, b: float, left: float, right: float, max_res: float, 
     return a + np.cumsum(cells)[:-1]
 
 
+def merge_close_lines(lines: np.ndarray, min_gap: float) -> np.ndarray:
+    """Hint lines closer than min_gap become ONE line at their mean (the outermost two lines stay where they are).
+
+    Independent hint sets — a port's [start, centre, stop], the nine bounding-box lines the multi-patch scene adds per metal
+    sheet, edge thirds — can land micrometres apart by accident: the reference's 2 x 2 array at a 61.2 mm pitch puts two y lines
+    6.8 um apart on a 3.4 mm mesh.  The toolkit the reference calls keeps such a pair and pays with the timestep (Courant on the
+    smallest cell: 2.3e-14 s, the excitation pulse alone then needs 104 000 timesteps, more than the scene's NrTS of 92 758 — the
+    run ends before the pulse does); here the pair is one line, moved by 3.4 um."""
+    a = np.asarray(lines, dtype=np.float64)
+    if a.size < 3 or min_gap <= 0:
+        return a
+    groups, cur = [], [a[0]]
+    for v in a[1:]:
+        if v - cur[-1] < min_gap:
+            cur.append(v)
+        else:
+            groups.append(cur); cur = [v]
+    groups.append(cur)
+    out = np.array([np.mean(g) for g in groups])
+    out[0], out[-1] = a[0], a[-1]
+    return out
+
+
+# lines closer than max_res / MERGE_FRACTION are merged before the fill-in (a 3.4 mm mesh: 34 um — below any drawn copper thickness)
+MERGE_FRACTION = 100.0
+
+
 def smooth_mesh_lines(lines: Iterable[float], max_res: float, ratio: float = 1.5) -> np.ndarray:
-    """All hint lines, plus graded fill-in so that no cell is larger than max_res."""
+    """The hint lines (pairs closer than max_res / 100 merged: merge_close_lines), plus graded fill-in so that no cell is larger than max_res."""
     out = unique_lines(lines)
     if out.size < 2:
         return out
     max_res = float(max_res)
+    out = merge_close_lines(out, max_res / MERGE_FRACTION)
     for _ in range(10 * out.size + 1000):
         d = np.diff(out)
         big = np.nonzero(d > max_res * (1 + 1e-9))[0]

@@ -15,13 +15,27 @@ def test_smooth_mesh_lines_invariants():
         out = m.smooth_mesh_lines(hints, 4.08, 1.4)
         d = np.diff(out)
         assert np.all(d > 0) and d.max() <= 4.08 * (1 + 1e-9)
-        for h in hints:
-            assert np.min(np.abs(out - h)) < 1e-9          # every hint line survives
+        for h in hints:                                     # every hint line survives — or, where two random hints fell closer than
+            assert np.min(np.abs(out - h)) < 4.08 / 100     # max_res / 100, as ONE line at their mean (merge_close_lines)
+        assert d.min() >= 4.08 / 100
         # grading: away from forced hint lines the neighbour ratio stays within `ratio`
         ratio = np.maximum(d[1:] / d[:-1], d[:-1] / d[1:])
-        forced = np.array([np.min(np.abs(hints - x)) < 1e-9 for x in out])
+        forced = np.array([np.min(np.abs(hints - x)) < 4.08 / 100 for x in out])
         free = ~(forced[1:-1])
         assert np.all(ratio[free] <= 1.4 * 1.02)
+
+
+def test_hint_lines_micrometres_apart_become_one():
+    """Independent hint sets landing 6.8 um apart (the reference's 2 x 2 array at a 61.2 mm pitch, y axis) on a 3.4 mm mesh: one line,
+    so that the Courant timestep is set by the mesh and not by the accident; the outermost lines and everything else stay."""
+    m = pkg("mesher")
+    hints = [-80.0, -31.9245, -31.9177, -10.0, 0.0, 0.4, 0.8, 29.2755, 29.2823, 80.0]
+    out = m.smooth_mesh_lines(hints, 3.4, 1.4)
+    assert np.diff(out).min() >= 0.034 and out[0] == -80.0 and out[-1] == 80.0
+    assert np.min(np.abs(out - (-31.9211))) < 1e-9 and np.min(np.abs(out - 29.2789)) < 1e-9
+    for h in (-10.0, 0.0, 0.4, 0.8):
+        assert np.min(np.abs(out - h)) < 1e-12
+    assert np.array_equal(m.merge_close_lines(np.array([0.0, 0.001, 1.0, 1.9995, 2.0]), 0.01), [0.0, 1.0, 2.0])   # the ends do not move
 
 
 def test_thirds_rule_hint():
