@@ -155,6 +155,13 @@ class Simulation:
             delta = (l[-1] - l[-2]) if f % 2 else (l[1] - l[0])
             self.mur_coeff[f] = (C0 * self.dt - delta) / (C0 * self.dt + delta)
         self.signal = gauss_pulse(self.f0, self.fc, self.dt)
+        # (openEMS prints "Requested excitation pulse would be N timesteps ... Cutting to max number of timesteps!" here and goes on; so do we)
+        self.excitation_warning = None
+        if len(self.signal) > self.nr_ts:
+            self.excitation_warning = (f"the excitation pulse is {len(self.signal)} timesteps long (dt = {self.dt:.3e} s: smallest cell "
+                                       f"{min(float(np.min(np.diff(l))) for l in grid.lines) * 1e6:.1f} um) but NrTS = {self.nr_ts}: the run ends before the pulse does")
+            import warnings
+            warnings.warn(self.excitation_warning, RuntimeWarning, stacklevel=2)
         # NF2FF recording
         self.nf2ff_box: Optional[NF2FFBox] = None
         self.nf2ff_warning: Optional[str] = None

@@ -656,7 +656,8 @@ def run_prepared_hip(prepared: FDTDPrepared, *, frequency_hz: float, verbose: in
                      "energy_db": float(st.energy_db), "cells": fdtd.sim.grid.ncells,
                      "grid": list(fdtd.sim.grid.shape), "schedule_fallback": getattr(st, "schedule_fallback", None),
                      "halo_transports_failed": list(getattr(st, "transports_failed", ())),
-                     "nf2ff_warning": getattr(fdtd.sim, "nf2ff_warning", None)}
+                     "nf2ff_warning": getattr(fdtd.sim, "nf2ff_warning", None),
+                     "excitation_warning": getattr(fdtd.sim, "excitation_warning", None)}
         if verbose:
             print(f"[fdtd-hip] done: {st.steps} steps, {st.mcells_per_s:.0f} MC/s, Dmax {10 * np.log10(Dmax):.2f} dBi", flush=True)
         return out

@@ -25,6 +25,18 @@ def test_smooth_mesh_lines_invariants():
         assert np.all(ratio[free] <= 1.4 * 1.02)
 
 
+def test_excitation_longer_than_the_run_is_flagged():
+    import warnings
+    wl, sc, simm = pkg("workloads"), pkg("scene"), pkg("simulation")
+    w = wl.patch_workload("t", nx=40, ny=40, nz=30)
+    vox = sc.voxelize(w.scene, w.grid)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        s = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="PEC", nr_ts=50)
+        assert s.excitation_warning and "NrTS = 50" in s.excitation_warning and any("ends before the pulse" in str(c.message) for c in caught)
+        assert simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="PEC", nr_ts=len(s.signal)).excitation_warning is None
+
+
 def test_hint_lines_micrometres_apart_become_one():
     """Independent hint sets landing 6.8 um apart (the reference's 2 x 2 array at a 61.2 mm pitch, y axis) on a 3.4 mm mesh: one line,
     so that the Courant timestep is set by the mesh and not by the accident; the outermost lines and everything else stay."""
@@ -247,7 +259,7 @@ def test_nf2ff_box_on_a_metal_sheet_is_flagged():
         vox = sc.voxelize(w.scene, w.grid)
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
-            s = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=10, nr_ts=10, nf2ff_freqs=[w.f0])
+            s = simm.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary="CPML", cpml_cells=10, nr_ts=100000, nf2ff_freqs=[w.f0])
         return s, [c for c in caught if issubclass(c.category, RuntimeWarning)]
     s, caught = build(wl.patch_workload("third-below", nx=100, ny=100, nz=40))
     assert s.nf2ff_warning and "z-min face (node plane 12)" in s.nf2ff_warning and len(caught) == 1
