@@ -19,6 +19,10 @@ def pkg(mod: str = ""):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # engine-parity tests step synthetic set-ups for a few hundred timesteps: shorter than the pulse, NF2FF faces wherever the drawn planes
+    # put them — what Simulation rightly warns a USER about (the tests of the warnings themselves record them explicitly)
+    config.addinivalue_line("filterwarnings", "ignore:the excitation pulse is:RuntimeWarning")
+    config.addinivalue_line("filterwarnings", "ignore:.*of the NF2FF box's:RuntimeWarning")
 
 
 @pytest.fixture(scope="session")
