@@ -390,5 +390,7 @@ class Simulation:
             boxes = self.nf2ff_box.collect(self.engine, self._nf_ids)
         if allreduce is not None:
             boxes = [allreduce(b) for b in boxes]
-        scale = self.dt * self.dft_every
+        # single-sided spectra, as the port spectra of LumpedPort.CalcPort (2 dt sum u exp(-jwt): [EXT] openEMS's convention for both): with the
+        # factor 2 on one side only, Prad / P_acc of a loss-free antenna reads 25 % (tests/test_tutorial_kat_cpu.py: power balance)
+        scale = 2.0 * self.dt * self.dft_every
         return [b * scale for b in boxes]

@@ -32,6 +32,21 @@ def test_tutorial_patch_s11_dip_and_directivity(oracle_lib, tmp_path):
     assert np.max(np.abs(r["s11"])) < 1.0 + 1e-3
 
 
+def test_power_balance_of_the_tutorial_patch(oracle_lib, tmp_path):
+    """The one check that sees the ABSOLUTE scale of the two post-processing chains against each other (S11 and directivity are ratios
+    inside one chain each): the power the port delivers at the resonance, 0.5 Re(U I*) from LumpedPort.CalcPort, against the power that
+    leaves through the NF2FF box, nf2ff.Prad — what the openEMS tutorial prints as its radiation efficiency.  Loss-free substrate, PEC
+    metal: everything accepted is radiated, 100 % (found at 25 % in round 3: single-sided port spectra, two-sided NF2FF spectra); with
+    the tutorial's loss tangent of 1e-3 the dielectric takes Q_rad / Q_d ~ 4 %."""
+    free = tutorial_scene.build_and_run(oracle_lib, str(tmp_path / "free"), loss_tangent=0.0)
+    eff = free["Prad"] / free["P_acc"]
+    assert free["dip_dB"] < -10.0 and 0.97 <= eff <= 1.03, eff
+    lossy = tutorial_scene.build_and_run(oracle_lib, str(tmp_path / "lossy"))
+    eff_l = lossy["Prad"] / lossy["P_acc"]
+    assert 0.90 <= eff_l <= 0.985 and eff_l < eff, (eff_l, eff)
+    assert lossy["P_acc"] <= lossy["P_inc"] * (1 + 1e-9)
+
+
 def test_recorder_equals_running_dft_on_the_oracle(oracle_lib):
     f0 = 2.45e9
     freqs = np.array([0.8 * f0, f0, 1.17 * f0])

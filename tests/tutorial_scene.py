@@ -10,7 +10,7 @@ import numpy as np
 from conftest import pkg
 
 
-def build_and_run(lib, sim_path, nr_ts=60000, end_criteria=1e-5, verbose=0, f_ff=None, post=True, **fdtd_kw):
+def build_and_run(lib, sim_path, nr_ts=60000, end_criteria=1e-5, verbose=0, f_ff=None, post=True, loss_tangent=1e-3, full_sphere=False, **fdtd_kw):
     """f_ff: evaluate the far field THERE instead of at the S11 dip; post=False: Run() only (a rank that leaves the
     post-processing to rank 0); fdtd_kw: backend options of openems_api.openEMS (rank=, world=, comm=, ...)."""
     oa = pkg("openems_api")
@@ -34,7 +34,7 @@ def build_and_run(lib, sim_path, nr_ts=60000, end_criteria=1e-5, verbose=0, f_ff
     patch = csx.AddMetal("patch")
     patch.AddBox(priority=10, start=[-patch_w / 2, -patch_l / 2, h], stop=[patch_w / 2, patch_l / 2, h])
     fdtd.AddEdges2Grid(dirs="xy", properties=patch, metal_edge_res=res / 2)
-    substrate = csx.AddMaterial("substrate", epsilon=eps_r, kappa=2 * np.pi * f0 * EPS0 * eps_r * 1e-3)
+    substrate = csx.AddMaterial("substrate", epsilon=eps_r, kappa=2 * np.pi * f0 * EPS0 * eps_r * loss_tangent)
     substrate.AddBox(priority=0, start=[-sub / 2, -sub / 2, 0.0], stop=[sub / 2, sub / 2, h])
     mesh.AddLine("z", np.linspace(0.0, h, 5).tolist())
     gnd = csx.AddMetal("gnd")
@@ -55,9 +55,12 @@ def build_and_run(lib, sim_path, nr_ts=60000, end_criteria=1e-5, verbose=0, f_ff
     s11_dB = 20 * np.log10(np.abs(s11))
     k = int(np.argmin(s11_dB))
     theta = np.arange(0.0, 181.0, 2.0)
-    ff = nf2ff.CalcNF2FF(sim_path, f[k] if f_ff is None else f_ff, theta, [0.0, 90.0], center=[0.0, 0.0, 1e-3])
+    phi = np.arange(0.0, 360.0, 6.0) if full_sphere else [0.0, 90.0]
+    ff = nf2ff.CalcNF2FF(sim_path, f[k] if f_ff is None else f_ff, theta, phi, center=[0.0, 0.0, 1e-3])
     return {"f": f, "s11": s11, "s11_dB": s11_dB, "f_dip": float(f[k]), "dip_dB": float(s11_dB[k]),
             "Dmax": float(np.asarray(ff.Dmax)[0]), "E_norm": np.asarray(ff.E_norm[0]), "theta": theta,
             "grid": fdtd.sim.grid.shape, "steps": fdtd.stats.steps, "energy_db": float(fdtd.stats.energy_db),
             "u": np.asarray(port.u_data.ui_val[0]), "i": np.asarray(port.i_data.ui_val[0]),
-            "nf2ff_mode": fdtd.sim.nf2ff_mode}
+            "nf2ff_mode": fdtd.sim.nf2ff_mode,
+            # absolute powers at the far-field frequency: radiated (flux through the NF2FF box) and accepted at the port
+            "Prad": float(np.asarray(ff.Prad)[0]), "P_acc": float(port.P_acc[k]), "P_inc": float(port.P_inc[k])}
