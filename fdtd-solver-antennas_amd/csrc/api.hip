@@ -837,6 +837,12 @@ static bool wavefront_active(const fdtd_ctx* c) {
   // boundary saves — 200x200x40 without CPML: 83.5 Gcells/s with two launches, 76.5 with one; with CPML 55.6 -> 57.1)
   const size_t blocks = (size_t)c->d.nk * c->p.nstrips * c->p.nbs;   // per sweep
   if (c->d.world == 1) return big || c->have_cpml || blocks >= 3000;
+  // Slabs that SHARE a device with a neighbour (several contexts of one process on one GPU, or several ranks on one GPU: the test boxes)
+  // take two launches: a one-launch kernel keeps blocks resident that spin on a neighbour's halo, and with several such kernels on one
+  // chip the spinning blocks can hold every slot while the kernel they wait for cannot get one (six slabs of 1 864 small blocks per
+  // sweep, four of them one-launch: a 10 s halo timeout, found by tests/fuzz_parity.py --slabs).  On its own GPU a slab cannot starve
+  // its neighbour.  (FDTD_FLAG_LOOPBACK: a slab timed ALONE as it runs in an N-GPU job keeps the N-GPU rule.)
+  if (!(c->d.flags & FDTD_FLAG_LOOPBACK) && (c->link_info[0][7] == 1 || c->link_info[1][7] == 1)) return false;
   // slabs on the mailbox transport: when a sweep is more than one round of resident blocks (an interior north-star slab whose
   // halos go to itself: 20 planes 29.5 -> 25.3 us per step with one launch; 15 planes 23.3 -> 25.4, 8 planes 17.8 -> 19.8)
   return big || blocks >= 1800;

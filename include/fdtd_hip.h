@@ -73,7 +73,10 @@ enum {
                                     timestep (WAVEFRONT below) where it is possible — no Mur faces, at least 2 planes, rows of at most
                                     30 720 cells — AND: on a single slab, when the fields exceed the 256 MiB Infinity Cache, or the slab
                                     has CPML layers, or a sweep has >= 3000 blocks of 1024 cells; on a slab of a decomposed grid (p2p
-                                    mailbox transport only), when the fields exceed the Infinity Cache or a sweep has >= 1800 blocks.
+                                    mailbox transport only), when the fields exceed the Infinity Cache or a sweep has >= 1800 blocks —
+                                    unless a neighbour's slab lives on the SAME device (fdtd_p2p_link_info: same_device; several slabs
+                                    of one process, or several ranks, on one GPU): the resident blocks of several one-launch kernels
+                                    that spin on each other's halos can starve one another on a shared chip.
                                     Else two launches (three with Mur faces).  Slabs of different size may therefore step under
                                     different schedules in one run; the results do not depend on it. */
   FDTD_FLAG_KERNEL_DIRECT = 1,   /* the same, named explicitly */

@@ -1,4 +1,5 @@
-"""Every plugin variant at the reference's default settings on the GPU: resonance, S11, Dmax, warnings (physics sanity, not parity)."""
+"""Every plugin variant at the reference's default settings on the GPU: resonance, S11, Dmax, radiated / accepted power at the S11 minimum,
+warnings (physics sanity, not parity).  python tools/plugin_variants_physics.py   # on a GPU box"""
 import importlib, sys, time, tempfile, os, warnings
 import numpy as np
 sys.path.insert(0, "/root/repo")
@@ -34,5 +35,13 @@ for name, prep_fn, f in cases:
     line = f"{name:26s} grid {st['grid']} steps {st['steps']:6d} energy {st['energy_db']:7.1f} dB  {st['mcells_per_s']/1e3:6.1f} Gcells/s  call {dt:5.2f} s  Dmax {10*np.log10(res.Dmax):6.2f} dBi  max intensity {np.max(res.intensity):6.2f}"
     if s11 is not None:
         k = int(np.argmin(s11)); line += f"  S11 min {s11[k]:6.1f} dB at {res.freq[k]/1e9:.3f} GHz (f_res {res.f_res/1e9:.3f})"
+        try:      # power balance at the S11 minimum: radiated (flux through the NF2FF box) over accepted at the first port
+            fr = float(res.freq[k])
+            nfr = prep.nf.CalcNF2FF(prep.sim_path, [fr], np.arange(0.0, 181.0, 6.0), np.arange(0.0, 360.0, 12.0), center=[0, 0, 0])
+            prep.port.CalcPort(prep.sim_path, np.array([fr]))
+            acc = sum(float(p.CalcPort(prep.sim_path, np.array([fr])).P_acc[0]) for p in (prep.ports or [prep.port]))
+            line += f"  Prad/P_acc {100 * float(np.asarray(nfr.Prad)[0]) / acc:5.1f} %"
+        except Exception as exc:      # noqa: BLE001
+            line += f"  (power balance: {exc})"
     line += f"  warnings: {[str(w.message)[:60] for w in ws]} {st.get('nf2ff_warning')}"
     print(line, flush=True)
