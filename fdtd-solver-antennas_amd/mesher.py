@@ -4,8 +4,8 @@ Restates what the reference asks of the external toolkit through
 ``FDTD.AddEdges2Grid(dirs, properties, metal_edge_res)`` and ``mesh.SmoothMeshLines('all', res, 1.4)``
 (antenna_sim/solver_fdtd_openems_fixed.py:193,210,217): [EXT] openEMS automesh / CSXCAD
 SmoothMeshLines.  Their source is not available here, so line positions are NOT pinned against
-them; the invariants are (tests/test_host_logic_cpu.py::test_mesher_*): every hint line is kept (pairs closer than max_res / 100
-become one line at their mean: merge_close_lines), no cell exceeds max_res, neighbouring cells differ by at most `ratio` wherever
+them; the invariants are (tests/test_host_logic_cpu.py::test_mesher_*): every hint line is kept (an isolated pair closer than max_res / 100
+becomes one line at its middle: merge_close_lines), no cell exceeds max_res, neighbouring cells differ by at most `ratio` wherever
 the hints allow it.
 """
 from __future__ import annotations
@@ -69,35 +69,43 @@ def _graded_fill(a: float, b: float, left: float, right: float, max_res: float, 
     return a + np.cumsum(cells)[:-1]
 
 
-def merge_close_lines(lines: np.ndarray, min_gap: float) -> np.ndarray:
-    """Hint lines closer than min_gap become ONE line at their mean (the outermost two lines stay where they are).
+def merge_close_lines(lines: np.ndarray, min_gap: float, lone: float = 0.125) -> np.ndarray:
+    """A pair of hint lines closer than min_gap AND closer than `lone` x the gaps on either side of it becomes ONE line at its middle (the
+    outermost two lines stay where they are).
 
     Independent hint sets — a port's [start, centre, stop], the nine bounding-box lines the multi-patch scene adds per metal
     sheet, edge thirds — can land micrometres apart by accident: the reference's 2 x 2 array at a 61.2 mm pitch puts two y lines
-    6.8 um apart on a 3.4 mm mesh.  The toolkit the reference calls keeps such a pair and pays with the timestep (Courant on the
-    smallest cell: 2.3e-14 s, the excitation pulse alone then needs 104 000 timesteps, more than the scene's NrTS of 92 758 — the
-    run ends before the pulse does); here the pair is one line, moved by 3.4 um."""
+    6.8 um apart (their neighbours 78 and 106 um away) on a 3.4 mm mesh.  The toolkit the reference calls keeps such a pair and pays with
+    the timestep (Courant on the smallest cell: 2.3e-14 s, the excitation pulse alone then needs 104 000 timesteps, more than the scene's
+    NrTS of 92 758 — the run ends before the pulse does); here the pair is one line, moved by 3.4 um.  Lines that are close ON PURPOSE
+    — the five lines across a 0.254 mm substrate under a 900 MHz mesh are 63 um apart, max_res / 100 there is 110 um — have equally close
+    neighbours and stay."""
     a = np.asarray(lines, dtype=np.float64)
-    if a.size < 3 or min_gap <= 0:
+    if min_gap <= 0:
         return a
-    groups, cur = [], [a[0]]
-    for v in a[1:]:
-        if v - cur[-1] < min_gap:
-            cur.append(v)
-        else:
-            groups.append(cur); cur = [v]
-    groups.append(cur)
-    out = np.array([np.mean(g) for g in groups])
-    out[0], out[-1] = a[0], a[-1]
-    return out
+    while a.size >= 4:
+        d = np.diff(a)
+        left = np.concatenate([[np.inf], d[:-1]])
+        right = np.concatenate([d[1:], [np.inf]])
+        cand = np.nonzero((d < min_gap) & (d < lone * np.minimum(left, right)))[0]
+        if cand.size == 0:
+            break
+        i = int(cand[np.argmin(d[cand])])
+        mid = 0.5 * (a[i] + a[i + 1])
+        if i == 0:
+            mid = a[0]
+        elif i + 1 == a.size - 1:
+            mid = a[-1]
+        a = np.concatenate([a[:i], [mid], a[i + 2:]])
+    return a
 
 
-# lines closer than max_res / MERGE_FRACTION are merged before the fill-in (a 3.4 mm mesh: 34 um — below any drawn copper thickness)
+# isolated pairs of lines closer than max_res / MERGE_FRACTION are merged before the fill-in (a 3.4 mm mesh: 34 um)
 MERGE_FRACTION = 100.0
 
 
 def smooth_mesh_lines(lines: Iterable[float], max_res: float, ratio: float = 1.5) -> np.ndarray:
-    """The hint lines (pairs closer than max_res / 100 merged: merge_close_lines), plus graded fill-in so that no cell is larger than max_res."""
+    """The hint lines (isolated pairs closer than max_res / 100 merged: merge_close_lines), plus graded fill-in so that no cell is larger than max_res."""
     out = unique_lines(lines)
     if out.size < 2:
         return out

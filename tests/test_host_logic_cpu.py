@@ -17,7 +17,6 @@ def test_smooth_mesh_lines_invariants():
         assert np.all(d > 0) and d.max() <= 4.08 * (1 + 1e-9)
         for h in hints:                                     # every hint line survives — or, where two random hints fell closer than
             assert np.min(np.abs(out - h)) < 4.08 / 100     # max_res / 100, as ONE line at their mean (merge_close_lines)
-        assert d.min() >= 4.08 / 100
         # grading: away from forced hint lines the neighbour ratio stays within `ratio`
         ratio = np.maximum(d[1:] / d[:-1], d[:-1] / d[1:])
         forced = np.array([np.min(np.abs(hints - x)) < 4.08 / 100 for x in out])
@@ -48,6 +47,11 @@ def test_hint_lines_micrometres_apart_become_one():
     for h in (-10.0, 0.0, 0.4, 0.8):
         assert np.min(np.abs(out - h)) < 1e-12
     assert np.array_equal(m.merge_close_lines(np.array([0.0, 0.001, 1.0, 1.9995, 2.0]), 0.01), [0.0, 1.0, 2.0])   # the ends do not move
+    # lines that are close ON PURPOSE keep their equally close neighbours: five lines across a 0.254 mm substrate under an 11 mm mesh
+    sub = [-150.0, -40.0, 0.0, 0.0635, 0.127, 0.1905, 0.254, 40.0, 150.0]
+    out = m.smooth_mesh_lines(sub, 11.0, 1.4)
+    for h in sub:
+        assert np.min(np.abs(out - h)) < 1e-12
 
 
 def test_thirds_rule_hint():

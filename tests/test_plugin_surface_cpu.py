@@ -207,3 +207,26 @@ def test_never_raises_returns_ok_false():
     assert not res.ok and res.message == bad.message
     pr = s.probe_hip("/nonexistent/dir")
     assert not pr.ok
+
+
+@pytest.mark.parametrize("f_ghz,er,h_mm", [(0.9, 4.3, 0.254), (5.8, 10.2, 3.2), (2.45, 2.2, 0.8)])
+def test_every_variant_sets_up_over_a_range_of_designs(oracle_lib, tmp_path, f_ghz, er, h_mm):
+    """Substrates from a hundredth to a fifteenth of the mesh resolution, permittivities 2.2 ... 10.2: every variant prepares and sets its
+    engine up — mesh, voxels, operator, a lumped port with a non-zero length (five lines 63 um apart across a 0.254 mm substrate under an
+    11 mm mesh must survive the merging of accidentally close hint lines), NF2FF box — and says so when the pulse outlasts the reference's
+    NrTS (0.9 GHz on 0.254 mm: 64 um cells, the pulse needs 31 000 of the 30 000 timesteps; openEMS prints its own warning there)."""
+    import warnings
+    s = pkg("solver_fdtd_hip")
+    p = pkg("params").PatchAntennaParams.from_user_units(frequency_ghz=f_ghz, er=er, h_mm=h_mm, loss_tangent=0.002)
+    for n, prep_fn in enumerate((s.prepare_hip_patch_fixed, s.prepare_hip_microstrip_patch, s.prepare_hip_microstrip_patch_3d, s.prepare_hip_patch)):
+        prep = prep_fn(p, work_dir=str(tmp_path / f"v{n}"), lib=oracle_lib)
+        assert prep.ok, prep.message
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            prep.FDTD.Run(prep.sim_path, verbose=0, cleanup=False, setup_only=True)
+        sim = prep.FDTD.sim
+        assert min(float(np.min(np.diff(l))) for l in sim.grid.lines) > 5e-6 and sim.grid.ncells < 5e6
+        assert (sim.excitation_warning is not None) == (len(sim.signal) > sim.nr_ts)
+        if (f_ghz, h_mm) == (0.9, 0.254) and prep_fn is not s.prepare_hip_patch:
+            assert sim.excitation_warning and "ends before the pulse" in sim.excitation_warning
+        sim.engine.close()
