@@ -98,3 +98,37 @@ def test_every_reference_solver_file_runs_on_the_shims(oracle_lib, tmp_path, mon
     assert res.ok, res.message
     inten = np.asarray(res.intensity)
     assert inten.shape == shape and np.isfinite(inten).all() and 3.0 < inten.max() < 13.0
+
+
+def test_plugin_signatures_are_the_references(monkeypatch):
+    """Every keyword a caller of the reference's probe / prepare / run_prepared functions may pass exists, with the same default, on the
+    function that replaces it (`dll_dir` is accepted and optional here; only the default work directories are named differently)."""
+    import importlib
+    import inspect
+    compat = os.path.join(ROOT, "fdtd-solver-antennas_amd", "compat")
+    monkeypatch.syspath_prepend(REF)
+    monkeypatch.syspath_prepend(compat)
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    if not hasattr(os, "add_dll_directory"):
+        monkeypatch.setattr(os, "add_dll_directory", lambda p: None, raising=False)
+    for m in [k for k in sys.modules if k.split(".")[0] in ("openEMS", "CSXCAD", "antenna_sim")]:
+        monkeypatch.delitem(sys.modules, m)
+    s = pkg("solver_fdtd_hip")
+    pairs = [("solver_fdtd_openems_fixed", "probe_openems_fixed", "probe_hip"),
+             ("solver_fdtd_openems_fixed", "prepare_openems_patch_fixed", "prepare_hip_patch_fixed"),
+             ("solver_fdtd_openems_fixed", "run_prepared_openems_fixed", "run_prepared_hip"),
+             ("solver_fdtd_openems_microstrip", "prepare_openems_microstrip_patch", "prepare_hip_microstrip_patch"),
+             ("solver_fdtd_openems_microstrip", "run_prepared_openems_microstrip", "run_prepared_hip"),
+             ("solver_fdtd_openems_microstrip_3d", "prepare_openems_microstrip_patch_3d", "prepare_hip_microstrip_patch_3d"),
+             ("solver_fdtd_openems_microstrip_3d", "run_prepared_openems_microstrip_3d", "run_prepared_hip"),
+             ("solver_fdtd_openems_microstrip_multi_3d", "prepare_openems_microstrip_multi_3d", "prepare_hip_microstrip_multi_3d"),
+             ("solver_fdtd_openems_microstrip_multi_3d", "run_prepared_openems_microstrip_multi_3d", "run_prepared_hip"),
+             ("solver_fdtd_openems", "prepare_openems_patch", "prepare_hip_patch"),
+             ("solver_fdtd_openems", "run_prepared_openems", "run_prepared_hip")]
+    for module, ref_name, own_name in pairs:
+        ref = inspect.signature(getattr(importlib.import_module("antenna_sim." + module), ref_name)).parameters
+        own = inspect.signature(getattr(s, own_name)).parameters
+        for name, par in ref.items():
+            assert name in own, f"{own_name} lacks {name!r} of {ref_name}"
+            if par.default is not inspect.Parameter.empty and name not in ("work_dir", "dll_dir"):
+                assert own[name].default == par.default, f"{own_name}({name}=...) defaults to {own[name].default!r}, {ref_name} to {par.default!r}"
