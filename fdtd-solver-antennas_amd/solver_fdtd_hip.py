@@ -641,7 +641,15 @@ def run_prepared_hip(prepared: FDTDPrepared, *, frequency_hz: float, verbose: in
             intensity, is_dbi = legacy_pattern(res, th.size, ph.size)
             th_out, ph_out = th, ph
         else:
-            intensity, is_dbi = pattern_to_dBi(np.asarray(res.E_norm[0]), Dmax, prepared.variant), True
+            e_norm = np.asarray(res.E_norm[0])
+            d_ref = Dmax
+            if prepared.variant in ("microstrip_3d", "multi_3d") and e_norm.ndim == 2 and e_norm.size and float(e_norm.max()) > 0:
+                # The reference calls CalcNF2FF once per phi and keeps the Dmax of the FIRST call (microstrip_3d.py:224-237, multi_3d.py:620-633:
+                # "expected to be constant") — but a call's Dmax is 4 pi max(P_rad) / Prad over the angles of THAT call, the phi[0] cut.  One
+                # transform of the whole grid here; the same number: Dmax scaled by the cut's share of the peak.  (Equal whenever the
+                # peak is at theta = 0, which lies in every cut; a two-element array peaked off broadside by 0.14 dB.)
+                d_ref = Dmax * (float(e_norm[:, 0].max()) / float(e_norm.max())) ** 2
+            intensity, is_dbi = pattern_to_dBi(e_norm, d_ref, prepared.variant), True
             th_out, ph_out = np.deg2rad(th_deg), np.deg2rad(ph_deg)
         out = FDTDResult(True, f"fdtd-hip FDTD completed ({prepared.variant})", theta=th_out,
                          phi=ph_out, intensity=intensity, sim_path=sim_path, is_dBi=is_dbi, Dmax=Dmax)

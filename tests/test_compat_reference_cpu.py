@@ -50,6 +50,11 @@ def test_reference_solver_runs_on_compat_shims(oracle_lib, tmp_path, monkeypatch
     assert res.is_dBi and res.intensity.shape == (90, 2)
     assert 3.0 < res.intensity.max() < 9.5
     assert np.allclose(res.phi, [0.0, np.pi / 2])
+    s = pkg("solver_fdtd_hip")
+    own = s.prepare_hip_patch_fixed(p, work_dir=str(tmp_path / "own"), lib=oracle_lib)
+    own.FDTD.NrTS = 4000
+    mine = s.run_prepared_hip(own, frequency_hz=2.45e9, verbose=0)
+    assert mine.ok and np.max(np.abs(np.asarray(mine.intensity) - np.asarray(res.intensity))) < 1e-9      # the mirrored plugin == the reference's own code
 
 
 VARIANTS = [
@@ -98,6 +103,23 @@ def test_every_reference_solver_file_runs_on_the_shims(oracle_lib, tmp_path, mon
     assert res.ok, res.message
     inten = np.asarray(res.intensity)
     assert inten.shape == shape and np.isfinite(inten).all() and 3.0 < inten.max() < 13.0
+    # ... and the mirrored plugin function of this package, given the same input, returns the SAME result: same mesh, same engine, same
+    # post-processing and conversion — the reference's Python, line by line, against this package's restatement of it, end to end
+    s = pkg("solver_fdtd_hip")
+    own_prep = {"solver_fdtd_openems_microstrip": s.prepare_hip_microstrip_patch, "solver_fdtd_openems_microstrip_3d": s.prepare_hip_microstrip_patch_3d,
+                "solver_fdtd_openems": s.prepare_hip_patch, "solver_fdtd_openems_microstrip_multi_3d": s.prepare_hip_microstrip_multi_3d}[module]
+    if "multi" in module:
+        own_arg = [s.PatchInstance(a.name, p, a.center_x_m, a.center_y_m, a.center_z_m, s.FeedDirection.NEG_X) for a in arg]
+        own = own_prep(own_arg, work_dir=str(tmp_path / "own"), theta_step_deg=2.0, phi_step_deg=5.0, mesh_quality=1, lib=oracle_lib)
+    else:
+        own = own_prep(p, work_dir=str(tmp_path / "own"), lib=oracle_lib)
+    assert own.ok, own.message
+    own.FDTD.NrTS = prep.FDTD.NrTS
+    mine = s.run_prepared_hip(own, frequency_hz=2.45e9, verbose=0)
+    assert mine.ok, mine.message
+    assert own.FDTD.sim.grid.shape == prep.FDTD.sim.grid.shape
+    assert np.allclose(mine.theta, res.theta, rtol=0, atol=1e-12) and np.allclose(mine.phi, res.phi, rtol=0, atol=1e-12)
+    assert np.max(np.abs(np.asarray(mine.intensity) - inten)) < 1e-9
 
 
 def test_plugin_signatures_are_the_references(monkeypatch):
