@@ -59,9 +59,9 @@ class FeedDirection(str, Enum):
 class PatchInstance:
     name: str
     params: PatchAntennaParams
-    center_x_m: float
-    center_y_m: float
-    center_z_m: float
+    center_x_m: float = 0.0          # (defaults as upstream: multi_patch_designer.py:18-28)
+    center_y_m: float = 0.0
+    center_z_m: float = 0.0
     feed_direction: FeedDirection = FeedDirection.NEG_X
     rot_x_deg: float = 0.0
     rot_y_deg: float = 0.0

@@ -309,3 +309,22 @@ def test_closed_form_design_equals_the_reference_over_random_inputs(monkeypatch)
         o = own_params.PatchAntennaParams.from_user_units(**kw)
         for name in ("frequency_hz", "eps_r", "h_m", "loss_tangent", "patch_length_m", "patch_width_m"):
             assert getattr(r, name) == getattr(o, name) or np.isclose(getattr(r, name), getattr(o, name), rtol=1e-15, atol=0), name
+
+
+def test_patch_instance_fields_and_defaults_are_the_references():
+    """`multi_patch_designer.PatchInstance` (`:18-28`) cannot be imported here (the module pulls in Tk and matplotlib); its dataclass is read
+    from the source text: same field names, same order, same defaults (positions default to 0.0: `PatchInstance("A", params)` must work)."""
+    import ast
+    import dataclasses
+    tree = ast.parse(open(os.path.join(REF, "antenna_sim", "multi_patch_designer.py")).read())
+    cls = next(n for n in ast.walk(tree) if isinstance(n, ast.ClassDef) and n.name == "PatchInstance")
+    ref_fields = [(st.target.id, None if st.value is None else ast.unparse(st.value)) for st in cls.body if isinstance(st, ast.AnnAssign)]
+    own = dataclasses.fields(pkg("solver_fdtd_hip").PatchInstance)
+    assert [f.name for f in own] == [n for n, _ in ref_fields]
+    for f, (name, default) in zip(own, ref_fields):
+        if default is None:
+            assert f.default is dataclasses.MISSING, name
+        elif default.startswith("FeedDirection."):
+            assert f.default.name == default.split(".")[1], name
+        else:
+            assert f.default == float(default), name
