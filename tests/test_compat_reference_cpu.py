@@ -328,3 +328,34 @@ def test_patch_instance_fields_and_defaults_are_the_references():
             assert f.default.name == default.split(".")[1], name
         else:
             assert f.default == float(default), name
+
+
+def test_probe_prepared_result_types_hold_every_field_of_the_references(monkeypatch):
+    """OpenEMSProbe / OpenEMSPrepared / OpenEMSResult of every solver file: each field exists, with the same default, on FDTDProbe / FDTDPrepared /
+    FDTDResult (which add fields: port, ports, variant, freq, s11, ...; never rename or drop one)."""
+    import dataclasses
+    import importlib
+    compat = os.path.join(ROOT, "fdtd-solver-antennas_amd", "compat")
+    monkeypatch.syspath_prepend(REF)
+    monkeypatch.syspath_prepend(compat)
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    if not hasattr(os, "add_dll_directory"):
+        monkeypatch.setattr(os, "add_dll_directory", lambda p: None, raising=False)
+    for m in [k for k in sys.modules if k.split(".")[0] in ("openEMS", "CSXCAD", "antenna_sim")]:
+        monkeypatch.delitem(sys.modules, m)
+    s = pkg("solver_fdtd_hip")
+    seen = 0
+    for module in ("solver_fdtd_openems_fixed", "solver_fdtd_openems_microstrip", "solver_fdtd_openems_microstrip_3d",
+                   "solver_fdtd_openems_microstrip_multi_3d", "solver_fdtd_openems"):
+        ref = importlib.import_module("antenna_sim." + module)
+        for ref_name, own in (("OpenEMSProbe", s.FDTDProbe), ("OpenEMSPrepared", s.FDTDPrepared), ("OpenEMSResult", s.FDTDResult)):
+            rc = getattr(ref, ref_name, None)
+            if rc is None or not dataclasses.is_dataclass(rc):
+                continue
+            own_fields = {f.name: f for f in dataclasses.fields(own)}
+            for f in dataclasses.fields(rc):
+                assert f.name in own_fields, f"{own.__name__} lacks {f.name!r} of {module}.{ref_name}"
+                if f.default is not dataclasses.MISSING:
+                    assert own_fields[f.name].default == f.default, (module, ref_name, f.name)
+                seen += 1
+    assert seen > 40
