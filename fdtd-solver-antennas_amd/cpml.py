@@ -35,17 +35,17 @@ class CPMLTables:
     nslot: list
     coef: list            # per axis float32 [2 (E-loc, H-loc)][3 (b, c, 1/kappa)][n_a]
 
-    def for_slab(self, k0: int, nk: int):
+    def for_slab(self, k0: int, nk: int, dtype=np.float32):
         """Slot maps + packed coefficient block for a z-slab [k0, k0+nk) (C ABI layout)."""
         sz = self.slot[2][k0:k0 + nk].copy()
         own = sz >= 0
         sz[own] = np.arange(int(own.sum()), dtype=np.int32)
         coef = np.concatenate([self.coef[0].ravel(), self.coef[1].ravel(),
-                               np.ascontiguousarray(self.coef[2][:, :, k0:k0 + nk]).ravel()]).astype(np.float32)
+                               np.ascontiguousarray(self.coef[2][:, :, k0:k0 + nk]).ravel()]).astype(dtype)
         return (self.slot[0], self.slot[1], sz, self.nslot[0], self.nslot[1], int(own.sum()), coef)
 
 
-def build_cpml(grid: RectGrid, dt: float, spec: CPMLSpec) -> CPMLTables:
+def build_cpml(grid: RectGrid, dt: float, spec: CPMLSpec, dtype=np.float32) -> CPMLTables:
     slots, nslots, coefs = [], [], []
     for a in range(3):
         l = grid.lines[a]
@@ -94,5 +94,5 @@ def build_cpml(grid: RectGrid, dt: float, spec: CPMLSpec) -> CPMLTables:
             coef[eh, 2, act] = 1.0 / kap[act]
         slots.append(slot)
         nslots.append(lo + hi + (1 if hi else 0))
-        coefs.append(coef.astype(np.float32))
+        coefs.append(coef.astype(dtype))
     return CPMLTables(slot=slots, nslot=nslots, coef=coefs)

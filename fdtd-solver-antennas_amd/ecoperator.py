@@ -182,9 +182,10 @@ def build_operator(grid: RectGrid, eps_r: np.ndarray, kappa: np.ndarray, pec: np
     return op
 
 
-def metric_lists(grid: RectGrid, dt: float):
+def metric_lists(grid: RectGrid, dt: float, dtype=np.float32):
     """Separable metric of the EC operator: vi = m * l[c] / (dd[a1] * dd[a2]);  iv = (dt/mu0) * dd[c] / (d[a1] * d[a2]).
-    emet[c][axis], hmet[c][axis] -> 1-D float32 tables over the whole grid."""
+    emet[c][axis], hmet[c][axis] -> 1-D float32 tables over the whole grid (`dtype`: the C ABI takes float32; float64 is what
+    the double-precision checker of the fp32 error budget is handed, tests/helpers.py)."""
     emet, hmet = [], []
     for c in range(3):
         et, ht = [None] * 3, [None] * 3
@@ -192,30 +193,30 @@ def metric_lists(grid: RectGrid, dt: float):
             if a == c:
                 l = grid.d[a].copy()
                 l[-1] = 0.0
-                et[a] = l.astype(np.float32)
-                ht[a] = (dt / MU0 * grid.dd[a]).astype(np.float32)
+                et[a] = l.astype(dtype)
+                ht[a] = (dt / MU0 * grid.dd[a]).astype(dtype)
             else:
-                et[a] = (1.0 / grid.dd[a]).astype(np.float32)
+                et[a] = (1.0 / grid.dd[a]).astype(dtype)
                 inv = 1.0 / grid.d[a]
                 inv[-1] = 0.0
-                ht[a] = inv.astype(np.float32)
+                ht[a] = inv.astype(dtype)
         emet.append(et)
         hmet.append(ht)
     return emet, hmet
 
 
-def pack_metric_tables(emet, hmet, grid: RectGrid, k0: int = 0, nk: Optional[int] = None):
+def pack_metric_tables(emet, hmet, grid: RectGrid, k0: int = 0, nk: Optional[int] = None, dtype=np.float32):
     """emet, hmet packed as [3][nx + ny + nk] float32 (z part local to the slab) — the C ABI's table argument."""
     nx, ny, nz = grid.shape
     nk = nz - k0 if nk is None else nk
     sl = slice(k0, k0 + nk)
-    e = np.concatenate([np.concatenate([t[0], t[1], t[2][sl]]) for t in emet]).astype(np.float32)
-    h = np.concatenate([np.concatenate([t[0], t[1], t[2][sl]]) for t in hmet]).astype(np.float32)
+    e = np.concatenate([np.concatenate([t[0], t[1], t[2][sl]]) for t in emet]).astype(dtype)
+    h = np.concatenate([np.concatenate([t[0], t[1], t[2][sl]]) for t in hmet]).astype(dtype)
     return e.reshape(3, nx + ny + nk), h.reshape(3, nx + ny + nk)
 
 
 def lumped_overrides(grid: RectGrid, eps_r: np.ndarray, kappa: np.ndarray, pec: np.ndarray, dt: float,
-                     lumped: Sequence[LumpedEdge]):
+                     lumped: Sequence[LumpedEdge], dtype=np.float32):
     """(global edge index int64, comp int8, vv float32, m float32) of the edges that carry a lumped conductance —
     the few coefficients the host fixes itself when the operator is built on the device (fdtd_build_operator)."""
     nx, ny, nz = grid.shape
@@ -235,9 +236,9 @@ def lumped_overrides(grid: RectGrid, eps_r: np.ndarray, kappa: np.ndarray, pec: 
         x = 0.5 * dt * G / C
         edge.append((k * ny + j) * nx + i)
         comp.append(c)
-        o_vv.append(np.float32((1.0 - x) / (1.0 + x)))
-        o_m.append(np.float32(dt / (eps_e * (1.0 + x))))
-    return (np.asarray(edge, np.int64), np.asarray(comp, np.int8), np.asarray(o_vv, np.float32), np.asarray(o_m, np.float32))
+        o_vv.append((1.0 - x) / (1.0 + x))
+        o_m.append(dt / (eps_e * (1.0 + x)))
+    return (np.asarray(edge, np.int64), np.asarray(comp, np.int8), np.asarray(o_vv, dtype), np.asarray(o_m, dtype))
 
 
 def _edge_scalar(cellval, grid, comp, pos):

@@ -16,12 +16,12 @@ def gauss_pulse_length(fc: float, dt: float) -> int:
     return int(np.ceil(2.0 * 9.0 / (2.0 * np.pi * fc) / dt))
 
 
-def gauss_pulse(f0: float, fc: float, dt: float, n: int | None = None) -> np.ndarray:
+def gauss_pulse(f0: float, fc: float, dt: float, n: int | None = None, dtype=np.float32) -> np.ndarray:
     n = gauss_pulse_length(fc, dt) if n is None else int(n)
     t = np.arange(n, dtype=np.float64) * dt
     t0 = 9.0 / (2.0 * np.pi * fc)
     s = np.cos(2.0 * np.pi * f0 * (t - t0)) * np.exp(-(2.0 * np.pi * fc * t / 3.0 - 3.0) ** 2)
-    return s.astype(np.float32)
+    return s.astype(dtype)
 
 
 def dft_twiddles(freqs, dt: float, every: int, nsamples: int, offset_steps: float = 0.0) -> np.ndarray:

@@ -149,11 +149,12 @@ class Simulation:
             spec = CPMLSpec(**{**self.bc.cpml.__dict__, "cells": cells})
             self.cpml = build_cpml(grid, self.dt, spec)
         self.mur_enable = np.array([1 if k == "MUR" else 0 for k in self.bc.kinds], np.int32)
-        self.mur_coeff = np.zeros(6, np.float32)
+        self.mur_coeff_f64 = np.zeros(6, np.float64)
         for f in range(6):
             l = grid.lines[f // 2]
             delta = (l[-1] - l[-2]) if f % 2 else (l[1] - l[0])
-            self.mur_coeff[f] = (C0 * self.dt - delta) / (C0 * self.dt + delta)
+            self.mur_coeff_f64[f] = (C0 * self.dt - delta) / (C0 * self.dt + delta)
+        self.mur_coeff = self.mur_coeff_f64.astype(np.float32)   # what the C ABI takes
         self.signal = gauss_pulse(self.f0, self.fc, self.dt)
         # (openEMS prints "Requested excitation pulse would be N timesteps ... Cutting to max number of timesteps!" here and goes on; so do we)
         self.excitation_warning = None

@@ -23,6 +23,14 @@
  *     psi  = fmaf(b, psi, c*d)            t = fmaf(ik, d, psi)
  *     curl = t1 - t2                      F = fmaf(cA, F, cB*curl)
  * Build with -ffp-contract=off -mfma (oracle/Makefile).
+ *
+ * PRECISION SWITCH: -DFDTD_REAL=double builds libfdtd_oracle_f64.so — the same algorithm and the same C
+ * ABI (float arrays in and out), with fields, psi, Mur state, operator coefficients, CPML tables, the excitation signal and
+ * the NF2FF records held and computed in double.  It bounds what float32 costs over a whole run (12 000-30 000 timesteps,
+ * solver_fdtd_openems_fixed.py:171): tests/fp32_error_budget.py, profiles/r04/fp32_error_budget.json.  Through the ABI's
+ * float tables the double build sees float32-ROUNDED coefficients (it then measures the rounding of the time stepping
+ * alone); the oracle-only entry fdtd_oracle_stage_f64() hands it the same tables in double before the setter that would
+ * take the float ones, so that the coefficient rounding is inside the measured difference as well.
  */
 #include "../include/fdtd_hip.h"
 
@@ -33,6 +41,16 @@
 #include <string.h>
 #include <stdarg.h>
 
+#ifndef FDTD_REAL
+#define FDTD_REAL float
+#endif
+typedef FDTD_REAL real;
+#define REAL_IS_DOUBLE (sizeof(real) == 8)
+/* a*b + c with ONE rounding in the working precision (the float build: fmaf, bit for bit what the HIP kernels do) */
+static inline real rfma(real a, real b, real c) { return REAL_IS_DOUBLE ? (real)fma((double)a, (double)b, (double)c) : (real)fmaf((float)a, (float)b, (float)c); }
+static void real_to_float(float* dst, const real* src, size_t n) { for (size_t q = 0; q < n; ++q) dst[q] = (float)src[q]; }
+static void float_to_real(real* dst, const float* src, size_t n) { for (size_t q = 0; q < n; ++q) dst[q] = (real)src[q]; }
+
 #define MAX_PROBES 64
 #define MAX_BOXES 64
 
@@ -40,7 +58,7 @@ typedef struct {
   int kind, n;
   int64_t* off; /* local flat offset into the padded field array */
   int8_t* comp;
-  float* w;
+  real* w;
   double* series;
 } probe_t;
 
@@ -50,30 +68,30 @@ typedef struct {
   int32_t olo[3], ohi[3];   /* owned part (global indices), empty if ohi<olo */
   size_t npts;
   double* acc;              /* running DFT: [nfreq][npts][2] */
-  float* rec;               /* recorder: [nsamples][npts] raw samples */
+  real* rec;                /* recorder: [nsamples][npts] raw samples */
 } dftbox_t;
 
 struct fdtd_ctx {
   fdtd_desc d;
   size_t plane, nloc;       /* ny*nx, nk*plane */
-  float* Vb[3]; float* Ib[3]; /* base allocations, (nk+2) planes */
-  float* V[3];  float* I[3];  /* pointers to local plane 0 */
-  float *vv, *vi, *ii, *iv;   /* [3][nloc] */
+  real* Vb[3]; real* Ib[3];   /* base allocations, (nk+2) planes */
+  real* V[3];  real* I[3];    /* pointers to local plane 0 */
+  real *vv, *vi, *ii, *iv;    /* [3][nloc] */
   int have_op;
   int op_ncls;      /* distinct (vv, m) pairs when the operator came in (or could go out) in class form, else 0 */
   /* CPML */
   int have_cpml;
   int32_t *slot[3]; int nslot[3];
-  float* coef;               /* [3][2][3][n_a] */
+  real* coef;                /* [3][2][3][n_a] */
   size_t coef_off[3];        /* start of each axis block */
-  float* psiE[3][2];         /* comp c, which (0: axis a1=(c+1)%3, 1: axis a2=(c+2)%3) */
-  float* psiH[3][2];
+  real* psiE[3][2];          /* comp c, which (0: axis a1=(c+1)%3, 1: axis a2=(c+2)%3) */
+  real* psiH[3][2];
   /* Mur */
-  int mur_on[6]; float mur_c[6];
-  float* mur_st[6][2];
+  int mur_on[6]; real mur_c[6];
+  real* mur_st[6][2];
   /* excitation */
-  float* sig; int nsig;
-  int nsrc; int64_t* src_off; int8_t* src_comp; float* src_amp; int32_t* src_delay;
+  real* sig; int nsig;
+  int nsrc; int64_t* src_off; int8_t* src_comp; real* src_amp; int32_t* src_delay;
   /* probes, dft */
   int nprobe; probe_t probe[MAX_PROBES];
   int nbox; dftbox_t box[MAX_BOXES];
@@ -96,6 +114,38 @@ static int fail(fdtd_ctx* c, int code, const char* fmt, ...) {
 void fdtd_oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 int fdtd_oracle_get_threads(void) { return omp_get_max_threads(); }
 
+int fdtd_oracle_real_bytes(void) { return (int)sizeof(real); }
+
+/* Double-precision tables for the double build (oracle-only; FDTD_E_UNSUPPORTED in the float build).  The C ABI hands every
+ * table over as float32; a table staged here (process-wide, one slot per kind) is taken INSTEAD by the next setter that would
+ * have taken the float one, and the slot is cleared: EMET / HMET / OVER_VV / OVER_M by fdtd_build_operator (same layout and
+ * length as its emet, hmet, over_vv, over_m arguments), CPML by fdtd_set_cpml (its coef argument), SIGNAL by fdtd_set_signal,
+ * MUR (6 values) by fdtd_set_mur.  (Source amplitudes and probe weights stay the ABI's floats: per-edge scale factors of the
+ * excitation and +-1 weights.) */
+enum { STAGE_EMET = 0, STAGE_HMET, STAGE_OVER_VV, STAGE_OVER_M, STAGE_CPML, STAGE_SIGNAL, STAGE_MUR, STAGE_KINDS };
+static double* g_stage[STAGE_KINDS];
+static size_t g_stage_n[STAGE_KINDS];
+int fdtd_oracle_stage_f64(int kind, const double* data, size_t n) {
+  if (kind < 0 || kind >= STAGE_KINDS) return FDTD_E_ARG;
+  free(g_stage[kind]); g_stage[kind] = NULL; g_stage_n[kind] = 0;
+  if (!data || !n) return FDTD_OK;              /* (clears the slot) */
+  if (!REAL_IS_DOUBLE) return FDTD_E_UNSUPPORTED;
+  g_stage[kind] = (double*)malloc(n * sizeof(double));
+  if (!g_stage[kind]) return FDTD_E_NOMEM;
+  memcpy(g_stage[kind], data, n * sizeof(double));
+  g_stage_n[kind] = n;
+  return FDTD_OK;
+}
+/* table `kind` of n entries in the working precision: the staged doubles when there are exactly n of them, else the floats */
+static real* take_table(int kind, const float* src, size_t n) {
+  real* d = (real*)malloc((n ? n : 1) * sizeof(real));
+  if (!d) return NULL;
+  const double* st = (g_stage[kind] && g_stage_n[kind] == n) ? g_stage[kind] : NULL;
+  for (size_t q = 0; q < n; ++q) d[q] = st ? (real)st[q] : (real)src[q];
+  free(g_stage[kind]); g_stage[kind] = NULL; g_stage_n[kind] = 0;
+  return d;
+}
+
 int fdtd_version(void) { return FDTD_ABI_VERSION; }
 int fdtd_device_count(void) { return 0; }
 const char* fdtd_backend(void) { return "oracle:cpu"; }
@@ -113,8 +163,8 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   c->plane = (size_t)d->nx * d->ny;
   c->nloc = c->plane * d->nk;
   for (int n = 0; n < 3; ++n) {
-    c->Vb[n] = (float*)calloc(c->plane * (d->nk + 2), sizeof(float));
-    c->Ib[n] = (float*)calloc(c->plane * (d->nk + 2), sizeof(float));
+    c->Vb[n] = (real*)calloc(c->plane * (d->nk + 2), sizeof(real));
+    c->Ib[n] = (real*)calloc(c->plane * (d->nk + 2), sizeof(real));
     if (!c->Vb[n] || !c->Ib[n]) { fdtd_destroy(c); return fail(NULL, FDTD_E_NOMEM, "fields"); }
     c->V[n] = c->Vb[n] + c->plane;
     c->I[n] = c->Ib[n] + c->plane;
@@ -139,7 +189,7 @@ void fdtd_destroy(fdtd_ctx* c) {
 }
 
 static int alloc_op(fdtd_ctx* c) {
-  size_t n = 3 * c->nloc * sizeof(float);
+  size_t n = 3 * c->nloc * sizeof(real);
   if (!c->vv) { c->vv = malloc(n); c->vi = malloc(n); c->ii = malloc(n); c->iv = malloc(n); }
   return (c->vv && c->vi && c->ii && c->iv) ? 0 : -1;
 }
@@ -147,8 +197,7 @@ static int alloc_op(fdtd_ctx* c) {
 int fdtd_set_operator_raw(fdtd_ctx* c, const float* vv, const float* vi, const float* ii, const float* iv) {
   if (!c || !vv || !vi || !ii || !iv) return fail(c, FDTD_E_ARG, "null operator array");
   if (alloc_op(c)) return fail(c, FDTD_E_NOMEM, "operator");
-  size_t n = 3 * c->nloc * sizeof(float);
-  memcpy(c->vv, vv, n); memcpy(c->vi, vi, n); memcpy(c->ii, ii, n); memcpy(c->iv, iv, n);
+  for (size_t q = 0; q < 3 * c->nloc; ++q) { c->vv[q] = (real)vv[q]; c->vi[q] = (real)vi[q]; c->ii[q] = (real)ii[q]; c->iv[q] = (real)iv[q]; }
   c->have_op = 1;
   c->op_ncls = 0;
   return FDTD_OK;
@@ -167,16 +216,16 @@ int fdtd_set_operator_classes(fdtd_ctx* c, const uint8_t* ecls, int ncls, const 
     const float *hx = hmet + n * tl, *hy = hx + nx, *hz = hy + ny;
     for (int k = 0; k < nk; ++k)
       for (int j = 0; j < ny; ++j) {
-        const float eyz = ey[j] * ez[k];
-        const float hyz = hy[j] * hz[k];
+        const real eyz = (real)ey[j] * (real)ez[k];
+        const real hyz = (real)hy[j] * (real)hz[k];
         size_t row = n * c->nloc + ((size_t)k * ny + j) * nx;
         for (int i = 0; i < nx; ++i) {
           int cl = ecls[row + i];
           if (cl >= ncls) return fail(c, FDTD_E_ARG, "class %d >= ncls %d", cl, ncls);
-          c->vv[row + i] = cls_vv[cl];
-          c->vi[row + i] = cls_m[cl] * (ex[i] * eyz);
-          c->ii[row + i] = 1.0f;
-          c->iv[row + i] = hx[i] * hyz;
+          c->vv[row + i] = (real)cls_vv[cl];
+          c->vi[row + i] = (real)cls_m[cl] * ((real)ex[i] * eyz);
+          c->ii[row + i] = (real)1;
+          c->iv[row + i] = (real)hx[i] * hyz;
         }
       }
   }
@@ -205,8 +254,16 @@ int fdtd_build_operator(fdtd_ctx* c, const double* dx, const double* dy, const d
   const double dt = c->d.dt;
   const size_t crow = (size_t)(nx - 1), cplane = (size_t)(nx - 1) * (ny - 1), gplane = (size_t)nx * ny;
   const int tl = nx + ny + nk;
-  float* mtmp = malloc(3 * c->nloc * sizeof(float));
-  if (!mtmp) return fail(c, FDTD_E_NOMEM, "operator");
+  real* mtmp = malloc(3 * c->nloc * sizeof(real));
+  /* the 1-D metric tables and the lumped-edge overrides in the working precision (double build: the staged doubles, if any) */
+  real* emet_r = take_table(STAGE_EMET, emet, (size_t)3 * tl);
+  real* hmet_r = take_table(STAGE_HMET, hmet, (size_t)3 * tl);
+  real* over_vv_r = take_table(STAGE_OVER_VV, over_vv, (size_t)n_over);
+  real* over_m_r = take_table(STAGE_OVER_M, over_m, (size_t)n_over);
+  if (!mtmp || !emet_r || !hmet_r || !over_vv_r || !over_m_r) {
+    free(mtmp); free(emet_r); free(hmet_r); free(over_vv_r); free(over_m_r);
+    return fail(c, FDTD_E_NOMEM, "operator");
+  }
   for (int n = 0; n < 3; ++n) {
     const int a1 = (n + 1) % 3, a2 = (n + 2) % 3;
 #pragma omp parallel for schedule(static)
@@ -217,7 +274,7 @@ int fdtd_build_operator(fdtd_ctx* c, const double* dx, const double* dy, const d
           const size_t e = n * c->nloc + ((size_t)k * ny + j) * nx + i;
           const int dead = pec[((size_t)n * nz + pos[2]) * gplane + (size_t)j * nx + i] != 0 || pos[n] == nn[n] - 1 ||
                            pos[a1] == 0 || pos[a1] == nn[a1] - 1 || pos[a2] == 0 || pos[a2] == nn[a2] - 1;
-          float vv = 0.f, m = 0.f;
+          real vv = 0, m = 0;
           if (!dead) {
             double ne = 0.0, nkp = 0.0, den = 0.0;
             for (int o1 = -1; o1 <= 0; ++o1)
@@ -233,8 +290,8 @@ int fdtd_build_operator(fdtd_ctx* c, const double* dx, const double* dy, const d
             const double eps_e = (ne / den) * eps0;
             const double kap_e = nkp / den;
             const double x = ((0.5 * dt) * kap_e) / eps_e;
-            vv = (float)((1.0 - x) / (1.0 + x));
-            m = (float)(dt / (eps_e * (1.0 + x)));
+            vv = (real)((1.0 - x) / (1.0 + x));
+            m = (real)(dt / (eps_e * (1.0 + x)));
           }
           c->vv[e] = vv;
           mtmp[e] = m;
@@ -242,12 +299,15 @@ int fdtd_build_operator(fdtd_ctx* c, const double* dx, const double* dy, const d
   }
   for (int q = 0; q < n_over; ++q) {
     const int64_t e = over_edge[q];
-    if (e < 0 || e >= (int64_t)nz * (int64_t)gplane || over_comp[q] < 0 || over_comp[q] > 2) { free(mtmp); return fail(c, FDTD_E_ARG, "override %d out of range", q); }
+    if (e < 0 || e >= (int64_t)nz * (int64_t)gplane || over_comp[q] < 0 || over_comp[q] > 2) {
+      free(mtmp); free(emet_r); free(hmet_r); free(over_vv_r); free(over_m_r);
+      return fail(c, FDTD_E_ARG, "override %d out of range", q);
+    }
     const int64_t kg = e / (int64_t)gplane;
     if (kg < k0 || kg >= k0 + nk) continue;
     const size_t l = (size_t)over_comp[q] * c->nloc + (size_t)(e - (int64_t)k0 * (int64_t)gplane);
-    c->vv[l] = over_vv[q];
-    mtmp[l] = over_m[q];
+    c->vv[l] = over_vv_r[q];
+    mtmp[l] = over_m_r[q];
   }
   /* what the compressed form would be: distinct (vv, m) pairs */
   {
@@ -258,7 +318,8 @@ int fdtd_build_operator(fdtd_ctx* c, const double* dx, const double* dy, const d
       memset(tab, 0xFF, TAB * sizeof(uint64_t));
       for (size_t e = 0; e < 3 * c->nloc && cnt <= 256; ++e) {
         uint32_t a, b;
-        memcpy(&a, &c->vv[e], 4); memcpy(&b, &mtmp[e], 4);
+        const float fa = (float)c->vv[e], fb = (float)mtmp[e];   /* (double build: pairs counted as the float build would see them) */
+        memcpy(&a, &fa, 4); memcpy(&b, &fb, 4);
         const uint64_t key = ((uint64_t)a << 32) | b;
         uint64_t h = key * 0x9E3779B97F4A7C15ull;
         size_t s = (size_t)(h >> 40) & (TAB - 1);
@@ -271,22 +332,22 @@ int fdtd_build_operator(fdtd_ctx* c, const double* dx, const double* dy, const d
   }
   /* expansion with the float32 association fixed by fdtd_hip.h */
   for (int n = 0; n < 3; ++n) {
-    const float *ex = emet + n * tl, *ey = ex + nx, *ez = ey + ny;
-    const float *hx = hmet + n * tl, *hy = hx + nx, *hz = hy + ny;
+    const real *ex = emet_r + n * tl, *ey = ex + nx, *ez = ey + ny;
+    const real *hx = hmet_r + n * tl, *hy = hx + nx, *hz = hy + ny;
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < nk; ++k)
       for (int j = 0; j < ny; ++j) {
-        const float eyz = ey[j] * ez[k];
-        const float hyz = hy[j] * hz[k];
+        const real eyz = ey[j] * ez[k];
+        const real hyz = hy[j] * hz[k];
         const size_t row = n * c->nloc + ((size_t)k * ny + j) * nx;
         for (int i = 0; i < nx; ++i) {
           c->vi[row + i] = mtmp[row + i] * (ex[i] * eyz);
-          c->ii[row + i] = 1.0f;
+          c->ii[row + i] = (real)1;
           c->iv[row + i] = hx[i] * hyz;
         }
       }
   }
-  free(mtmp);
+  free(mtmp); free(emet_r); free(hmet_r); free(over_vv_r); free(over_m_r);
   c->have_op = 1;
   return FDTD_OK;
 }
@@ -301,8 +362,7 @@ int fdtd_operator_form(fdtd_ctx* c, int* form, int* nclasses) {
 int fdtd_get_operator(fdtd_ctx* c, float* vv, float* vi, float* ii, float* iv) {
   if (!c || !vv || !vi || !ii || !iv) return fail(c, FDTD_E_ARG, "null argument");
   if (!c->have_op) return fail(c, FDTD_E_STATE, "operator not set");
-  const size_t n = 3 * c->nloc * sizeof(float);
-  memcpy(vv, c->vv, n); memcpy(vi, c->vi, n); memcpy(ii, c->ii, n); memcpy(iv, c->iv, n);
+  for (size_t q = 0; q < 3 * c->nloc; ++q) { vv[q] = (float)c->vv[q]; vi[q] = (float)c->vi[q]; ii[q] = (float)c->ii[q]; iv[q] = (float)c->iv[q]; }
   return FDTD_OK;
 }
 
@@ -332,26 +392,30 @@ int fdtd_set_cpml(fdtd_ctx* c, const int32_t* sx, const int32_t* sy, const int32
     off += (size_t)6 * n;
   }
   free(c->coef);
-  c->coef = (float*)malloc(off * sizeof(float));
-  memcpy(c->coef, coef, off * sizeof(float));
+  c->coef = take_table(STAGE_CPML, coef, off);
+  if (!c->coef) return fail(c, FDTD_E_NOMEM, "cpml tables");
   for (int n = 0; n < 3; ++n)
     for (int w = 0; w < 2; ++w) {
       int a = (n + 1 + w) % 3;
       free(c->psiE[n][w]); free(c->psiH[n][w]);
       size_t sz_ = psi_size(c, a);
-      c->psiE[n][w] = sz_ ? (float*)calloc(sz_, sizeof(float)) : NULL;
-      c->psiH[n][w] = sz_ ? (float*)calloc(sz_, sizeof(float)) : NULL;
+      c->psiE[n][w] = sz_ ? (real*)calloc(sz_, sizeof(real)) : NULL;
+      c->psiH[n][w] = sz_ ? (real*)calloc(sz_, sizeof(real)) : NULL;
     }
   c->have_cpml = 1;
   return FDTD_OK;
 }
 
-static const float* cpml_tab(const fdtd_ctx* c, int a, int eh, int which) {
+static const real* cpml_tab(const fdtd_ctx* c, int a, int eh, int which) {
   return c->coef + c->coef_off[a] + (size_t)(eh * 3 + which) * n_axis(c, a);
 }
 
 int fdtd_set_mur(fdtd_ctx* c, const int32_t enable[6], const float coeff[6]) {
   if (!c || !enable || !coeff) return fail(c, FDTD_E_ARG, "null mur argument");
+  real* co = take_table(STAGE_MUR, coeff, 6);
+  if (!co) return fail(c, FDTD_E_NOMEM, "mur");
+  for (int f = 0; f < 6; ++f) c->mur_c[f] = co[f];
+  free(co);
   for (int f = 0; f < 6; ++f) {
     int a = f / 2;
     int on = enable[f] != 0;
@@ -360,11 +424,11 @@ int fdtd_set_mur(fdtd_ctx* c, const int32_t enable[6], const float coeff[6]) {
       if (b < c->d.k0 || b >= c->d.k0 + c->d.nk) on = 0;
       else if (on && c->d.nk < 2) return fail(c, FDTD_E_UNSUPPORTED, "Mur z face needs nk >= 2");
     }
-    c->mur_on[f] = on; c->mur_c[f] = coeff[f];
+    c->mur_on[f] = on;
     size_t n = a == 0 ? (size_t)c->d.nk * c->d.ny : a == 1 ? (size_t)c->d.nk * c->d.nx : c->plane;
     for (int t = 0; t < 2; ++t) {
       free(c->mur_st[f][t]);
-      c->mur_st[f][t] = on ? (float*)calloc(n, sizeof(float)) : NULL;
+      c->mur_st[f][t] = on ? (real*)calloc(n, sizeof(real)) : NULL;
     }
   }
   return FDTD_OK;
@@ -373,8 +437,8 @@ int fdtd_set_mur(fdtd_ctx* c, const int32_t enable[6], const float coeff[6]) {
 int fdtd_set_signal(fdtd_ctx* c, const float* sig, int n) {
   if (!c || !sig || n < 1) return fail(c, FDTD_E_ARG, "bad signal");
   free(c->sig);
-  c->sig = (float*)malloc(n * sizeof(float));
-  memcpy(c->sig, sig, n * sizeof(float));
+  c->sig = take_table(STAGE_SIGNAL, sig, (size_t)n);
+  if (!c->sig) return fail(c, FDTD_E_NOMEM, "signal");
   c->nsig = n;
   return FDTD_OK;
 }
@@ -392,14 +456,14 @@ int fdtd_add_source(fdtd_ctx* c, int n, const int64_t* idx, const int8_t* comp, 
   int tot = c->nsrc + n;
   c->src_off = realloc(c->src_off, tot * sizeof(int64_t));
   c->src_comp = realloc(c->src_comp, tot * sizeof(int8_t));
-  c->src_amp = realloc(c->src_amp, tot * sizeof(float));
+  c->src_amp = realloc(c->src_amp, tot * sizeof(real));
   c->src_delay = realloc(c->src_delay, tot * sizeof(int32_t));
   for (int e = 0; e < n; ++e) {
     int64_t l = to_local(c, idx[e]);
     if (l == -2 || comp[e] < 0 || comp[e] > 2) return fail(c, FDTD_E_ARG, "source edge %d out of grid", e);
     if (l < 0) continue;
     c->src_off[c->nsrc] = l; c->src_comp[c->nsrc] = comp[e];
-    c->src_amp[c->nsrc] = amp[e]; c->src_delay[c->nsrc] = delay[e];
+    c->src_amp[c->nsrc] = (real)amp[e]; c->src_delay[c->nsrc] = delay[e];
     c->nsrc++;
   }
   return FDTD_OK;
@@ -411,7 +475,7 @@ int fdtd_add_probe(fdtd_ctx* c, int kind, int n, const int64_t* idx, const int8_
   probe_t* p = &c->probe[c->nprobe];
   memset(p, 0, sizeof(*p));
   p->kind = kind;
-  p->off = malloc((n + 1) * sizeof(int64_t)); p->comp = malloc(n + 1); p->w = malloc((n + 1) * sizeof(float));
+  p->off = malloc((n + 1) * sizeof(int64_t)); p->comp = malloc(n + 1); p->w = malloc((n + 1) * sizeof(real));
   p->series = calloc(c->d.max_steps > 0 ? c->d.max_steps : 1, sizeof(double));
   for (int e = 0; e < n; ++e) {
     int64_t l = to_local(c, idx[e]);
@@ -421,7 +485,7 @@ int fdtd_add_probe(fdtd_ctx* c, int kind, int n, const int64_t* idx, const int8_
       return fail(c, FDTD_E_ARG, "probe edge %d out of grid", e);
     }
     if (l < 0) continue;
-    p->off[p->n] = l; p->comp[p->n] = comp[e]; p->w[p->n] = w[e]; p->n++;
+    p->off[p->n] = l; p->comp[p->n] = comp[e]; p->w[p->n] = (real)w[e]; p->n++;
   }
   if (id_out) *id_out = c->nprobe;
   c->nprobe++;
@@ -473,7 +537,7 @@ int fdtd_add_dft_box(fdtd_ctx* c, int kind, int comp, const int32_t lo[3], const
   b->npts = b->ohi[2] < b->olo[2] ? 0 :
       (size_t)(b->ohi[0] - b->olo[0] + 1) * (b->ohi[1] - b->olo[1] + 1) * (b->ohi[2] - b->olo[2] + 1);
   if (c->recorder) {
-    b->rec = b->npts ? calloc(b->npts * (size_t)c->nsamples, sizeof(float)) : NULL;
+    b->rec = b->npts ? calloc(b->npts * (size_t)c->nsamples, sizeof(real)) : NULL;
     if (b->npts && !b->rec) return fail(c, FDTD_E_NOMEM, "recorder box: %zu samples", b->npts * (size_t)c->nsamples);
   } else {
     b->acc = b->npts ? calloc(b->npts * c->nfreq * 2, sizeof(double)) : NULL;
@@ -528,30 +592,30 @@ int fdtd_rec_transform(fdtd_ctx* c, int id, int nfreq, const double* tw, double*
  * ---------------------------------------------------------------------------------------- */
 
 /* CPML transform of one row of differences d[] taken along axis a (in place -> stretched term). */
-static void cpml_row(const fdtd_ctx* c, int a, int eh, float* psi_arr, int j, int k, float* d) {
+static void cpml_row(const fdtd_ctx* c, int a, int eh, real* psi_arr, int j, int k, real* d) {
   const int nx = c->d.nx, ny = c->d.ny;
-  const float *B = cpml_tab(c, a, eh, 0), *C = cpml_tab(c, a, eh, 1), *K = cpml_tab(c, a, eh, 2);
+  const real *B = cpml_tab(c, a, eh, 0), *C = cpml_tab(c, a, eh, 1), *K = cpml_tab(c, a, eh, 2);
   if (a == 0) {
     const int ns = c->nslot[0];
-    float* psi = psi_arr + ((size_t)k * ny + j) * ns;
+    real* psi = psi_arr + ((size_t)k * ny + j) * ns;
     for (int i = 0; i < nx; ++i) {
       int s = c->slot[0][i];
       if (s < 0) continue;
-      float p = fmaf(B[i], psi[s], C[i] * d[i]);
+      real p = rfma(B[i], psi[s], C[i] * d[i]);
       psi[s] = p;
-      d[i] = fmaf(K[i], d[i], p);
+      d[i] = rfma(K[i], d[i], p);
     }
   } else {
     int q = a == 1 ? j : k;
     int s = c->slot[a][q];
     if (s < 0) return;
-    float* psi = a == 1 ? psi_arr + ((size_t)k * c->nslot[1] + s) * nx
-                        : psi_arr + ((size_t)s * ny + j) * nx;
-    const float b = B[q], cc = C[q], kk = K[q];
+    real* psi = a == 1 ? psi_arr + ((size_t)k * c->nslot[1] + s) * nx
+                       : psi_arr + ((size_t)s * ny + j) * nx;
+    const real b = B[q], cc = C[q], kk = K[q];
     for (int i = 0; i < nx; ++i) {
-      float p = fmaf(b, psi[i], cc * d[i]);
+      real p = rfma(b, psi[i], cc * d[i]);
       psi[i] = p;
-      d[i] = fmaf(kk, d[i], p);
+      d[i] = rfma(kk, d[i], p);
     }
   }
 }
@@ -561,16 +625,16 @@ static void update_E(fdtd_ctx* c) {
   const ptrdiff_t st[3] = {1, nx, (ptrdiff_t)c->plane};
 #pragma omp parallel
   {
-    float* d1 = (float*)malloc(2 * nx * sizeof(float));
-    float* d2 = d1 + nx;
+    real* d1 = (real*)malloc(2 * nx * sizeof(real));
+    real* d2 = d1 + nx;
 #pragma omp for collapse(2) schedule(static)
     for (int k = 0; k < nk; ++k)
       for (int j = 0; j < ny; ++j) {
         const size_t row = ((size_t)k * ny + j) * nx;
         for (int n = 0; n < 3; ++n) {
           const int a1 = (n + 1) % 3, a2 = (n + 2) % 3;
-          const float* F2 = c->I[a2] + row; /* differenced along a1 */
-          const float* F1 = c->I[a1] + row; /* differenced along a2 */
+          const real* F2 = c->I[a2] + row; /* differenced along a1 */
+          const real* F1 = c->I[a1] + row; /* differenced along a2 */
           for (int i = 0; i < nx; ++i) {
             d1[i] = F2[i] - F2[i - st[a1]];
             d2[i] = F1[i] - F1[i - st[a2]];
@@ -579,10 +643,10 @@ static void update_E(fdtd_ctx* c) {
             cpml_row(c, a1, 0, c->psiE[n][0], j, k, d1);
             cpml_row(c, a2, 0, c->psiE[n][1], j, k, d2);
           }
-          float* V = c->V[n] + row;
-          const float* vv = c->vv + n * c->nloc + row;
-          const float* vi = c->vi + n * c->nloc + row;
-          for (int i = 0; i < nx; ++i) V[i] = fmaf(vv[i], V[i], vi[i] * (d1[i] - d2[i]));
+          real* V = c->V[n] + row;
+          const real* vv = c->vv + n * c->nloc + row;
+          const real* vi = c->vi + n * c->nloc + row;
+          for (int i = 0; i < nx; ++i) V[i] = rfma(vv[i], V[i], vi[i] * (d1[i] - d2[i]));
         }
       }
     free(d1);
@@ -594,16 +658,16 @@ static void update_H(fdtd_ctx* c) {
   const ptrdiff_t st[3] = {1, nx, (ptrdiff_t)c->plane};
 #pragma omp parallel
   {
-    float* d1 = (float*)malloc(2 * nx * sizeof(float));
-    float* d2 = d1 + nx;
+    real* d1 = (real*)malloc(2 * nx * sizeof(real));
+    real* d2 = d1 + nx;
 #pragma omp for collapse(2) schedule(static)
     for (int k = 0; k < nk; ++k)
       for (int j = 0; j < ny; ++j) {
         const size_t row = ((size_t)k * ny + j) * nx;
         for (int n = 0; n < 3; ++n) {
           const int a1 = (n + 1) % 3, a2 = (n + 2) % 3;
-          const float* F2 = c->V[a2] + row;
-          const float* F1 = c->V[a1] + row;
+          const real* F2 = c->V[a2] + row;
+          const real* F1 = c->V[a1] + row;
           for (int i = 0; i < nx; ++i) {
             d1[i] = F2[i] - F2[i + st[a1]];
             d2[i] = F1[i] - F1[i + st[a2]];
@@ -612,10 +676,10 @@ static void update_H(fdtd_ctx* c) {
             cpml_row(c, a1, 1, c->psiH[n][0], j, k, d1);
             cpml_row(c, a2, 1, c->psiH[n][1], j, k, d2);
           }
-          float* I = c->I[n] + row;
-          const float* ii = c->ii + n * c->nloc + row;
-          const float* iv = c->iv + n * c->nloc + row;
-          for (int i = 0; i < nx; ++i) I[i] = fmaf(ii[i], I[i], iv[i] * (d1[i] - d2[i]));
+          real* I = c->I[n] + row;
+          const real* ii = c->ii + n * c->nloc + row;
+          const real* iv = c->iv + n * c->nloc + row;
+          for (int i = 0; i < nx; ++i) I[i] = rfma(ii[i], I[i], iv[i] * (d1[i] - d2[i]));
         }
       }
     free(d1);
@@ -636,11 +700,11 @@ static void mur_pass(fdtd_ctx* c, int mode) {
     if (a == 2) { b = hi ? c->d.nz - 1 - c->d.k0 : 0 - c->d.k0; in = hi ? b - 1 : b + 1; }
     else { b = hi ? dim[a] - 1 : 0; in = hi ? b - 1 : b + 1; }
     const int p = (a + 1) % 3, q = (a + 2) % 3; /* in-face axes */
-    const float co = c->mur_c[f];
+    const real co = c->mur_c[f];
     for (int t = 0; t < 2; ++t) {
       const int comp = t == 0 ? p : q;
-      float* V = c->V[comp];
-      float* S = c->mur_st[f][t];
+      real* V = c->V[comp];
+      real* S = c->mur_st[f][t];
       /* storage index: the two in-face axes in (slow, fast) = (larger axis id, smaller axis id) */
       const int u = p < q ? p : q, v = p < q ? q : p; /* u fast, v slow */
       for (int iv_ = 0; iv_ < dim[v]; ++iv_)
@@ -648,8 +712,8 @@ static void mur_pass(fdtd_ctx* c, int mode) {
           size_t s = (size_t)iv_ * dim[u] + iu;
           ptrdiff_t base = (ptrdiff_t)iu * st[u] + (ptrdiff_t)iv_ * st[v];
           ptrdiff_t ob = base + (ptrdiff_t)b * st[a], oi = base + (ptrdiff_t)in * st[a];
-          if (mode == 0) S[s] = fmaf(-co, V[ob], V[oi]);
-          else if (mode == 1) S[s] = fmaf(co, V[oi], S[s]);
+          if (mode == 0) S[s] = rfma(-co, V[ob], V[oi]);
+          else if (mode == 1) S[s] = rfma(co, V[oi], S[s]);
           else V[ob] = S[s];
         }
     }
@@ -668,7 +732,7 @@ static void post_E(fdtd_ctx* c) {
 }
 
 static void sample(fdtd_ctx* c, int kind) {
-  float** F = kind == FDTD_KIND_V ? c->V : c->I;
+  real** F = kind == FDTD_KIND_V ? c->V : c->I;
   if (c->step < c->d.max_steps)
     for (int p = 0; p < c->nprobe; ++p) {
       probe_t* pr = &c->probe[p];
@@ -682,13 +746,13 @@ static void sample(fdtd_ctx* c, int kind) {
     for (int b = 0; b < c->nbox; ++b) {
       dftbox_t* bx = &c->box[b];
       if (bx->kind != kind || !bx->npts) continue;
-      const float* fld = F[bx->comp];
+      const real* fld = F[bx->comp];
       const int ni = bx->ohi[0] - bx->olo[0] + 1, nj = bx->ohi[1] - bx->olo[1] + 1, nkk = bx->ohi[2] - bx->olo[2] + 1;
-      float* dst = bx->rec + (size_t)smp * bx->npts;
+      real* dst = bx->rec + (size_t)smp * bx->npts;
       for (int kk = 0; kk < nkk; ++kk)
         for (int jj = 0; jj < nj; ++jj)
           memcpy(dst + ((size_t)kk * nj + jj) * ni,
-                 fld + ((size_t)(bx->olo[2] - c->d.k0 + kk) * c->d.ny + bx->olo[1] + jj) * c->d.nx + bx->olo[0], (size_t)ni * sizeof(float));
+                 fld + ((size_t)(bx->olo[2] - c->d.k0 + kk) * c->d.ny + bx->olo[1] + jj) * c->d.nx + bx->olo[0], (size_t)ni * sizeof(real));
     }
   }
   if (c->nfreq && c->step % c->every == 0) {
@@ -698,7 +762,7 @@ static void sample(fdtd_ctx* c, int kind) {
       for (int b = 0; b < c->nbox; ++b) {
         dftbox_t* bx = &c->box[b];
         if (bx->kind != kind || !bx->npts) continue;
-        const float* fld = F[bx->comp];
+        const real* fld = F[bx->comp];
         const int ni = bx->ohi[0] - bx->olo[0] + 1, nj = bx->ohi[1] - bx->olo[1] + 1, nkk = bx->ohi[2] - bx->olo[2] + 1;
         for (int f = 0; f < c->nfreq; ++f) {
           const double wr = tw[2 * f], wi = tw[2 * f + 1];
@@ -706,7 +770,7 @@ static void sample(fdtd_ctx* c, int kind) {
 #pragma omp parallel for collapse(2) schedule(static)
           for (int kk = 0; kk < nkk; ++kk)
             for (int jj = 0; jj < nj; ++jj) {
-              const float* src = fld + ((size_t)(bx->olo[2] - c->d.k0 + kk) * c->d.ny + bx->olo[1] + jj) * c->d.nx + bx->olo[0];
+              const real* src = fld + ((size_t)(bx->olo[2] - c->d.k0 + kk) * c->d.ny + bx->olo[1] + jj) * c->d.nx + bx->olo[0];
               double* a = acc + ((size_t)kk * nj + jj) * ni * 2;
               for (int ii_ = 0; ii_ < ni; ++ii_) {
                 double v = (double)src[ii_];
@@ -764,7 +828,7 @@ int fdtd_energy(fdtd_ctx* c, double sums[2]) {
   if (!c || !sums) return FDTD_E_ARG;
   double sv = 0.0, si = 0.0;
   for (int n = 0; n < 3; ++n) {
-    const float *V = c->V[n], *I = c->I[n];
+    const real *V = c->V[n], *I = c->I[n];
 #pragma omp parallel for reduction(+ : sv, si) schedule(static)
     for (size_t p = 0; p < c->nloc; ++p) { sv += (double)V[p] * V[p]; si += (double)I[p] * I[p]; }
   }
@@ -813,39 +877,39 @@ int fdtd_comm_nranks(fdtd_ctx* c, int* nranks) { if (!c || !nranks) return FDTD_
 
 int fdtd_halo_get(fdtd_ctx* c, int which, float* buf) {
   if (!c || !buf) return FDTD_E_ARG;
-  size_t n = c->plane * sizeof(float);
+  const size_t n = c->plane;
   if (which == FDTD_HALO_H_UP) {
-    memcpy(buf, c->I[0] + (size_t)(c->d.nk - 1) * c->plane, n);
-    memcpy(buf + c->plane, c->I[1] + (size_t)(c->d.nk - 1) * c->plane, n);
+    real_to_float(buf, c->I[0] + (size_t)(c->d.nk - 1) * c->plane, n);
+    real_to_float(buf + c->plane, c->I[1] + (size_t)(c->d.nk - 1) * c->plane, n);
   } else if (which == FDTD_HALO_E_DOWN) {
-    memcpy(buf, c->V[0], n);
-    memcpy(buf + c->plane, c->V[1], n);
+    real_to_float(buf, c->V[0], n);
+    real_to_float(buf + c->plane, c->V[1], n);
   } else return fail(c, FDTD_E_ARG, "bad halo id");
   return FDTD_OK;
 }
 
 int fdtd_halo_put(fdtd_ctx* c, int which, const float* buf) {
   if (!c || !buf) return FDTD_E_ARG;
-  size_t n = c->plane * sizeof(float);
+  const size_t n = c->plane;
   if (which == FDTD_HALO_H_UP) { /* ghost plane below */
-    memcpy(c->I[0] - c->plane, buf, n);
-    memcpy(c->I[1] - c->plane, buf + c->plane, n);
+    float_to_real(c->I[0] - c->plane, buf, n);
+    float_to_real(c->I[1] - c->plane, buf + c->plane, n);
   } else if (which == FDTD_HALO_E_DOWN) { /* ghost plane above */
-    memcpy(c->V[0] + c->nloc, buf, n);
-    memcpy(c->V[1] + c->nloc, buf + c->plane, n);
+    float_to_real(c->V[0] + c->nloc, buf, n);
+    float_to_real(c->V[1] + c->nloc, buf + c->plane, n);
   } else return fail(c, FDTD_E_ARG, "bad halo id");
   return FDTD_OK;
 }
 
 int fdtd_get_field(fdtd_ctx* c, int kind, int comp, float* out) {
   if (!c || !out || comp < 0 || comp > 2) return FDTD_E_ARG;
-  memcpy(out, (kind == FDTD_KIND_V ? c->V : c->I)[comp], c->nloc * sizeof(float));
+  real_to_float(out, (kind == FDTD_KIND_V ? c->V : c->I)[comp], c->nloc);
   return FDTD_OK;
 }
 
 int fdtd_set_field(fdtd_ctx* c, int kind, int comp, const float* in) {
   if (!c || !in || comp < 0 || comp > 2) return FDTD_E_ARG;
-  memcpy((kind == FDTD_KIND_V ? c->V : c->I)[comp], in, c->nloc * sizeof(float));
+  float_to_real((kind == FDTD_KIND_V ? c->V : c->I)[comp], in, c->nloc);
   return FDTD_OK;
 }
 

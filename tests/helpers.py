@@ -26,3 +26,55 @@ def rel_l2(a, b):
     a = np.asarray(a); b = np.asarray(b)
     n = np.linalg.norm(b.ravel())
     return float(np.linalg.norm((a - b).ravel()) / (n if n > 0 else 1.0))
+
+
+# ---- the double-precision build of the oracle (oracle/Makefile: libfdtd_oracle_f64.so) ---------------------------------
+# Same algorithm and C ABI as the float32 oracle, with state and coefficients in double: what float32 costs over a whole run.
+# The ABI's tables are float32; staged through the oracle-only fdtd_oracle_stage_f64 the double build takes the SAME tables
+# in double instead (metric, lumped-edge overrides, CPML coefficients, excitation signal, Mur coefficients).
+STAGE_EMET, STAGE_HMET, STAGE_OVER_VV, STAGE_OVER_M, STAGE_CPML, STAGE_SIGNAL, STAGE_MUR = range(7)
+
+
+def load_oracle_f64():
+    import ctypes, os
+    from conftest import ROOT
+    path = os.path.join(ROOT, "oracle", "libfdtd_oracle_f64.so")
+    lib = pkg("_capi").bind(ctypes.CDLL(path))
+    lib.fdtd_oracle_real_bytes.restype = ctypes.c_int
+    assert lib.fdtd_oracle_real_bytes() == 8
+    lib.fdtd_oracle_stage_f64.restype = ctypes.c_int
+    lib.fdtd_oracle_stage_f64.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+    return lib
+
+
+def stage_f64_tables(sim, lib64):
+    """Hand the double build the tables of `sim` in double (consumed by the setters of the next sim.build(lib64))."""
+    eco, cp, exc = pkg("ecoperator"), pkg("cpml"), pkg("excitation")
+    g, v = sim.grid, sim.vox
+    k0, nk = sim.slabs(1)[0]
+    f64 = np.float64
+
+    def stage(kind, arr):
+        a = np.ascontiguousarray(arr, dtype=f64)
+        rc = lib64.fdtd_oracle_stage_f64(kind, a.ctypes.data, a.size)
+        assert rc == 0, rc
+
+    assert sim.device_operator, "the double tables are staged for fdtd_build_operator"
+    emet, hmet = eco.pack_metric_tables(*eco.metric_lists(g, sim.dt, dtype=f64), g, k0, nk, dtype=f64)
+    stage(STAGE_EMET, emet); stage(STAGE_HMET, hmet)
+    _, _, o_vv, o_m = eco.lumped_overrides(g, v.eps_r, v.kappa, v.pec, sim.dt, v.lumped, dtype=f64)
+    stage(STAGE_OVER_VV, o_vv); stage(STAGE_OVER_M, o_m)
+    if sim.cpml is not None:
+        spec = cp.CPMLSpec(**{**sim.bc.cpml.__dict__, "cells": sim.bc.face_cells()})
+        stage(STAGE_CPML, cp.build_cpml(g, sim.dt, spec, dtype=f64).for_slab(k0, nk, dtype=f64)[-1])
+    if sim.mur_enable.any():
+        stage(STAGE_MUR, sim.mur_coeff_f64)
+    stage(STAGE_SIGNAL, exc.gauss_pulse(sim.f0, sim.fc, sim.dt, len(sim.signal), dtype=f64))
+
+
+def build_f64(sim, lib64, *, double_tables=True):
+    """sim.build(lib64) on the double build of the oracle.  double_tables=False: it sees the float32-rounded tables of the C ABI
+    (the difference to the float32 run is then the rounding of the time stepping alone); True: the same tables in double."""
+    if double_tables:
+        stage_f64_tables(sim, lib64)
+    return sim.build(lib64)
