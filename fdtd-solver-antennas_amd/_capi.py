@@ -40,7 +40,7 @@ class FdtdProfile(C.Structure):
                 ("steps", C.c_int32), ("fused", C.c_int32), ("ms_event_overhead", C.c_double)]
 
 
-FLAG_KERNEL_AUTO, FLAG_KERNEL_DIRECT, FLAG_KERNEL_WAVEFRONT, FLAG_KERNEL_MASK = 0, 1, 5, 0xF
+FLAG_KERNEL_AUTO, FLAG_KERNEL_DIRECT, FLAG_KERNEL_WAVEFRONT, FLAG_KERNEL_RESIDENT, FLAG_KERNEL_MASK = 0, 1, 5, 6, 0xF
 FLAG_OVERLAP_ON, FLAG_OVERLAP_OFF, FLAG_LOOPBACK = 0x20, 0x40, 0x80
 KIND_V, KIND_I = 0, 1
 PHASE_E, PHASE_H = 0, 1
@@ -410,7 +410,7 @@ class Engine:
         """Launches per timestep, lag, tiling and halo transport of this context (fdtd_schedule_info)."""
         a = np.zeros(8, np.int32)
         self._ck(self.lib.fdtd_schedule_info(self._ctx, _ptr(a)), "schedule_info")
-        return {"launches_per_timestep": int(a[0]), "lag_planes": int(a[1]), "rows_per_strip": int(a[2]),
+        return {"launches_per_timestep": int(a[0]), "lag_planes": int(a[1]), "resident": bool(a[1] == -1), "rows_per_strip": int(a[2]),
                 "blocks_per_sweep": int(a[3]),
                 "transport": ("none", "p2p", "rccl", "linked", "external")[int(a[4])] if 0 <= a[4] <= 4 else None,
                 "xcd_shares_weighted": bool(a[5]), "xcd_adaptations": int(a[6]), "timesteps_per_launch_max": int(a[7])}

@@ -185,6 +185,8 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   if (getenv("FDTD_MUR_UNFUSED")) c->mur_fuse_post = false;   // experiments: the Mur post pass as a launch of its own
   if (const char* v = getenv("FDTD_WAVEFRONT")) c->wf_mode = atoi(v) ? 1 : 0;
   if (const char* v = getenv("FDTD_WF_LAG")) c->wf_lag = std::max(0, std::min(4096, atoi(v)));
+  if (const char* v = getenv("FDTD_RESIDENT")) c->res_mode = atoi(v) ? 1 : 0;          // 1: the resident schedule whenever it is possible, 0: never
+  if (const char* v = getenv("FDTD_RES_CHUNK")) c->res_chunk = std::max(1, std::min(4096, atoi(v)));
   if (const char* v = getenv("FDTD_WF_MULTI")) c->wf_multi = std::max(1, std::min(4096, atoi(v)));   // timesteps per launch at most (1: one launch per timestep)
   if (const char* v = getenv("FDTD_OCC_H")) c->occ_h = std::max(0, std::min(16, atoi(v)));
   if (const char* v = getenv("FDTD_P2P_FAULT_STEP")) c->p2p_fault_step = atoll(v);   // test hook: see fdtd_run
@@ -211,6 +213,7 @@ void fdtd_destroy(fdtd_ctx* c) {
   hipFree(c->vv); hipFree(c->vi); hipFree(c->ii); hipFree(c->iv); hipFree(c->ecls); hipFree(c->lut); hipFree(c->met);
   hipFree(c->cpcoef); hipFree(c->xc_tab);
   hipFree(c->xstamp);
+  res_free(c);
   hipFree(c->wf_flags); hipFree(c->wf_err); hipFree(c->wf_flagsH); hipFree(c->wf_prb_sp); hipFree(c->wf_prb_blk); hipFree(c->wf_prb_rng);
   hipFree(c->wf_prbV_sp); hipFree(c->wf_prb_done);
   for (int n = 0; n < 12; ++n) hipFree(c->psi[n]);
@@ -848,6 +851,56 @@ static bool wavefront_active(const fdtd_ctx* c) {
   return big || blocks >= 1800;
 }
 
+// The grid resident in registers for the length of a launch (k_resident, resident.hip): small single slabs without CPML layers — the
+// reference GUI's default MUR scenes.  AUTO takes it for every such slab WITH Mur faces (three latency-bound launches per timestep
+// otherwise); FDTD_FLAG_KERNEL_RESIDENT / $FDTD_RESIDENT=1 take it wherever it is possible, DIRECT / WAVEFRONT / $FDTD_RESIDENT=0 never.
+static bool resident_active(fdtd_ctx* c) {
+  const unsigned sel = c->d.flags & FDTD_FLAG_KERNEL_MASK;
+  if (sel == FDTD_FLAG_KERNEL_DIRECT || sel == FDTD_FLAG_KERNEL_WAVEFRONT || c->res_mode == 0) return false;
+  if (!sources_fusable(c) || !res_possible(c, nullptr)) return false;
+  if (sel == FDTD_FLAG_KERNEL_RESIDENT || c->res_mode == 1) return true;
+  return c->any_mur;
+}
+static int res_check(fdtd_ctx* c) {
+  if (!c->res.err) return FDTD_OK;
+  int e = 0;
+  HIPCK(c, hipMemcpy(&e, c->res.err, sizeof(int), hipMemcpyDeviceToHost));
+  if (e) {
+    hipMemset(c->res.err, 0, sizeof(int));
+    return fdtd_fail(c, FDTD_E_DEVICE, "resident schedule: a workgroup waited more than 2 s for a neighbour tile's halo (not all workgroups resident at once?); the fields of this run are invalid — re-initialise them and select FDTD_FLAG_KERNEL_DIRECT (simulation.Simulation.run does both by itself)");
+  }
+  return FDTD_OK;
+}
+static int step_loop_res(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
+  HIPCK(c, hipSetDevice(c->d.device));
+  hipStream_t s = c->stream;
+  int r = res_prepare(c, c->res_chunk);
+  if (r) return r;
+  // NF2FF faces: the time-domain record is written by the kernel itself (res_record); running-DFT sums (k_dft) read the arrays, so there
+  // a launch ends at every sampled timestep
+  const bool sampling = c->nfreq && !c->recorder && c->nbox && c->every > 0;
+  int launches = 0;
+  for (int n = 0; n < nsteps;) {
+    int chunk = std::min(c->res_chunk, nsteps - n);
+    if (sampling) {   // ... so that the sampled timestep (a multiple of `every`) is the launch's last
+      const long long next = (c->step + c->every - 1) / c->every * c->every;
+      chunk = (int)std::min<long long>(chunk, next - c->step + 1);
+    }
+    if (pe) { c->kev0 = pe->e0[launches]; c->kev1 = pe->e1[launches]; }
+    r = launch_resident(c, c->step, chunk, s);
+    c->kev0 = c->kev1 = nullptr;
+    if (r) return r;
+    c->step += chunk;
+    if (sampling) launch_dft(c, -1, c->step - 1, s);
+    n += chunk;
+    ++launches;
+  }
+  c->mur_pre_step = -1;   // (the Mur state arrays are not kept by the resident kernel: the next two-launch timestep runs its own pre pass)
+  if (pe) pe->launches = launches;
+  HIPCK(c, hipGetLastError());
+  return FDTD_OK;
+}
+
 static void p2p_prime_if_needed(fdtd_ctx* c);
 static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   HIPCK(c, hipSetDevice(c->d.device));
@@ -900,12 +953,18 @@ static int wf_check(fdtd_ctx* c) {
 
 static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   const unsigned sel = c->d.flags & FDTD_FLAG_KERNEL_MASK;
-  if (sel > FDTD_FLAG_KERNEL_DIRECT && sel != FDTD_FLAG_KERNEL_WAVEFRONT)
+  if (sel == FDTD_FLAG_KERNEL_RESIDENT) {
+    const char* why = "";
+    if (!res_possible(c, &why)) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "resident schedule: %s", why);
+    if (!sources_fusable(c)) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "resident schedule: a source edge lies on or next to a Mur face");
+  }
+  if (sel > FDTD_FLAG_KERNEL_DIRECT && sel != FDTD_FLAG_KERNEL_WAVEFRONT && sel != FDTD_FLAG_KERNEL_RESIDENT)
     return fdtd_fail(c, FDTD_E_UNSUPPORTED, "kernel selection %u: the one-pass variants were removed (measured slower than the two-pass kernels on every workload)", sel);
   if (sel == FDTD_FLAG_KERNEL_WAVEFRONT && !wavefront_possible(c))
     return fdtd_fail(c, FDTD_E_UNSUPPORTED, "wavefront schedule: single slab or slabs on the p2p mailbox transport, no Mur faces, at least 2 planes, rows of at most %d cells", 30 * FDTD_BLOCK * 4);
   if (c->p.p2p) return step_loop_p2p(c, nsteps, pe);
   const bool multi = c->d.world > 1;
+  if (resident_active(c)) return step_loop_res(c, nsteps, pe);
   if (multi && !c->comm) return fdtd_fail(c, FDTD_E_STATE, "world > 1: call fdtd_p2p_attach (mailbox transport), fdtd_comm_init (RCCL), fdtd_link + fdtd_run_linked, or drive fdtd_half_step + fdtd_halo_*");
   if (wavefront_active(c)) return step_loop_wf(c, nsteps, pe);
   const bool fused = sources_fusable(c);
@@ -982,6 +1041,7 @@ int fdtd_run(fdtd_ctx* c, int nsteps) {
   HIPCK(c, hipStreamSynchronize(c->comm_stream));
   if (c->p.p2p) { r = p2p_check(c); if (r) return r; }
   if ((r = wf_check(c))) return r;
+  if ((r = res_check(c))) return r;
   return xcd_adapt(c);     // (a no-op unless the call's last launch was a calibration launch of the XCD shares)
 }
 
@@ -1034,12 +1094,13 @@ int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
     out->ms_event_overhead = 0.0;
     out->ms_update_e = se / nsteps;             // per TIMESTEP (launches of several timesteps: their durations summed, over the timesteps)
     out->ms_update_h = sh / nsteps;
-    out->fused = wavefront_active(c) ? 1 : 0;   // 1: ms_update_e is the one launch of a whole timestep, ms_update_h = 0
+    out->fused = (pe.launches >= 0) ? 1 : 0;   // 1: ms_update_e is the one launch of a whole timestep, ms_update_h = 0
     out->launches_e = nl; out->launches_h = out->fused ? 0 : nsteps;
   }
   destroy_all();
   if (r) return r;
   HIPCK(c, e);
+  if ((r = res_check(c))) return r;
   return wf_check(c);
 }
 
@@ -1413,15 +1474,19 @@ int fdtd_schedule_info(fdtd_ctx* c, int32_t info[8]) {
   for (int q = 0; q < 8; ++q) info[q] = 0;
   const bool multi = c->d.world > 1;
   const bool steppable = c->have_op && (!multi || c->p.p2p || c->comm || c->link_lo || c->link_hi);
-  const bool wf = steppable && wavefront_active(c);
-  info[0] = !steppable ? 0 : wf ? 1 : !c->any_mur ? 2 : (sources_fusable(c) && !multi && c->mur_fuse_post) ? 3 : 5;
-  info[1] = wf ? wf_lag_for(c) : 0;
+  const bool res = steppable && resident_active(c);
+  const bool wf = steppable && !res && wavefront_active(c);
+  info[0] = !steppable ? 0 : res ? 1 : wf ? 1 : !c->any_mur ? 2 : (sources_fusable(c) && !multi && c->mur_fuse_post) ? 3 : 5;
+  info[1] = res ? -1 : wf ? wf_lag_for(c) : 0;
   info[2] = c->p.tys;
   info[3] = c->d.nk * c->p.nstrips * c->p.nbs;
   info[4] = !multi ? 0 : c->p.p2p ? 1 : c->comm ? 2 : (c->link_lo || c->link_hi) ? 3 : 4;
   info[5] = (c->xcd_balance && c->have_cpml) ? 1 : 0;
   info[6] = c->xcd_adapt_done;
-  info[7] = wf ? wf_multi_max(c) : 0;
+  info[7] = res ? c->res_chunk : wf ? wf_multi_max(c) : 0;
+  if (res) {   // tiles instead of strip blocks
+    if (res_prepare(c, c->res_chunk) == FDTD_OK) { info[2] = c->res.nstrips; info[3] = c->res.nblocks; }
+  }
   return FDTD_OK;
 }
 

@@ -131,6 +131,20 @@ struct DevBox   { int kind, comp; int lo[3]; int ni, nj, nkk; double* acc; long 
 
 struct MurFace { int on; float coeff; float* st[2]; int n; };
 
+// host side of the resident schedule (resident.hip): tiling, per-tile source / probe-cell tables, the granule exchange buffer
+struct ResHost {
+  bool built = false;
+  int nzt = 0, nstrips = 0, nblocks = 0;
+  int* d_kt = nullptr; int* d_jt = nullptr;
+  float* gx = nullptr; unsigned tag = 0;
+  int2* d_src_rng = nullptr; int* d_src_ids = nullptr;
+  int2* d_prb_rng = nullptr; int4* d_prb_cells = nullptr; int* d_slot0 = nullptr;
+  float* stage = nullptr; int nslots = 1, chunk_cap = 0;
+  int* err = nullptr;
+  int nsrc_seen = -1, nprobe_seen = -1;
+  int capacity = -1, capacity_variant = -1;   // workgroups of k_resident the chip holds at once (occupancy query), for which kernel variant
+};
+
 struct fdtd_ctx {
   fdtd_desc d{};
   DevParams p{};
@@ -153,6 +167,9 @@ struct fdtd_ctx {
   long long wf_fault_step = -1;  // test hook ($FDTD_WF_FAULT_STEP): at that step the H blocks wait for a flag value nobody publishes
   unsigned* wf_flagsH = nullptr; int* wf_prb_sp = nullptr; int* wf_prb_blk = nullptr; int2* wf_prb_rng = nullptr;
   int* wf_prbV_sp = nullptr; unsigned* wf_prb_done = nullptr;
+  int res_mode = -1;             // grid resident in registers (k_resident): -1 auto, 0 never, 1 whenever possible; $FDTD_RESIDENT
+  int res_chunk = 256;           // timesteps per resident launch at most; $FDTD_RES_CHUNK
+  ResHost res;
   int wf_multi = 64;             // timesteps per launch at most (cache-resident single slabs without Mur faces); 1 = one launch per timestep; $FDTD_WF_MULTI
   bool wf_prb_dirty = true;      // probe tables of the wavefront launch need rebuilding (a probe was added)
   std::vector<int> h_prb_off[FDTD_MAX_PROBES];   // local offsets of every probe's cells (host copy)
@@ -247,6 +264,11 @@ void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);   // runn
 void launch_rec_dft(const float* rec, long npts, int ns, int nfreq, const double* d_tw, double* d_out, hipStream_t s);
 void launch_energy(fdtd_ctx* c, hipStream_t s);
 void choose_tiling(fdtd_ctx* c);
+// resident.hip: small grids resident in registers for the length of a launch
+bool res_possible(fdtd_ctx* c, const char** why);
+int res_prepare(fdtd_ctx* c, int max_chunk);
+int launch_resident(fdtd_ctx* c, long long step, int nsteps, hipStream_t s);
+void res_free(fdtd_ctx* c);
 void xcd_shares_reset(fdtd_ctx* c);   // after the CPML layers or the tiling changed
 int xcd_stamp_arm(fdtd_ctx* c, hipStream_t s);   // the next k_step launch leaves its blocks' end times (calibration)
 int xcd_adapt(fdtd_ctx* c);              // after that launch has finished: per-XCD finish times -> new share fractions

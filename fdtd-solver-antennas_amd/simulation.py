@@ -334,7 +334,8 @@ class Simulation:
                     # waits too long for an earlier block's flag sets an error word and the run comes back invalid
                     # (never a hang).  Heal it here: a new context under the two-launch schedule (no flags, no
                     # dependence on dispatch order), same process, from the initial state — once.
-                    if not (fresh and self.world == 1 and "wavefront schedule" in str(exc) and stats.schedule_fallback is None):
+                    if not (fresh and self.world == 1 and ("wavefront schedule" in str(exc) or "resident schedule" in str(exc))
+                            and stats.schedule_fallback is None):
                         raise
                     log(f"[fdtd-hip] {exc} — repeating the run under the two-launch schedule")
                     e.close()

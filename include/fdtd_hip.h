@@ -91,6 +91,13 @@ enum {
                                     blocks of the next timestep start while the H blocks of this one drain.  DIRECT never takes it.
                                     Results are identical to the two-pass kernels bit for bit.  fdtd_profile.fused = 1: ms_update_e is the
                                     main-launch time per timestep. */
+  FDTD_FLAG_KERNEL_RESIDENT = 6, /* the grid RESIDENT IN REGISTERS for the length of a launch (csrc/resident.hip): a workgroup owns a tile
+                                    (1-2 planes x a few rows x all of x), keeps its fields and coefficients in registers over up to 256
+                                    timesteps (cut at the timesteps whose NF2FF faces are sampled) and exchanges tile halos as data-tagged
+                                    granules through a device-scope buffer — one ~1 us hop per half-step instead of a kernel boundary.
+                                    Single slab, PEC / Mur faces (no CPML layers), rows of at most 1024 cells (256 with Mur z faces), no
+                                    more tiles than the chip holds resident workgroups (else FDTD_E_UNSUPPORTED).  AUTO takes it for
+                                    every such slab with Mur faces: the reference GUI's default scenes.  Results identical bit for bit. */
   FDTD_FLAG_KERNEL_MASK   = 0xF,
   FDTD_FLAG_OVERLAP_ON    = 0x20, /* multi-slab: split sweeps into interior + halo-dependent plane (the default) */
   FDTD_FLAG_OVERLAP_OFF   = 0x40, /* multi-slab: one launch per sweep, after the halo has arrived */
@@ -229,7 +236,9 @@ int fdtd_get_step(fdtd_ctx* ctx, int64_t* step);
 /* The step schedule this context runs under its current flags, boundaries and transport:
  *   info[0] main-kernel launches per timestep (1: k_step, 2: update_E + update_H, 3: with Mur faces; 0: driven by
  *           fdtd_half_step / not steppable yet)
- *   info[1] one launch per timestep only: planes the E sweep runs ahead of the H sweep (== nk: all E blocks, then all H blocks)
+ *   info[1] one launch per timestep only: planes the E sweep runs ahead of the H sweep (== nk: all E blocks, then all H blocks);
+ *           -1: the resident schedule (FDTD_FLAG_KERNEL_RESIDENT: info[0] = 1, info[2] = strips, info[3] = tiles = workgroups,
+ *           info[7] = timesteps one launch may hold)
  *   info[2] rows per strip, info[3] blocks (of 1024 cells) per sweep
  *   info[4] halo transport: 0 none (single slab), 1 p2p mailbox, 2 RCCL, 3 linked contexts, 4 external (fdtd_half_step)
  *   info[5] 1 if the XCD shares are cost-weighted (CPML layers present)
