@@ -732,6 +732,13 @@ static bool sources_fusable(const fdtd_ctx* c) {
   return true;
 }
 
+// a main-kernel launch the runtime refused (kernels.hip: launch_main keeps the first one): reported once, as an error code
+static int launch_status(fdtd_ctx* c) {
+  const int r = c->launch_failed;
+  c->launch_failed = 0;
+  return r;
+}
+
 struct ProfEvents {
   std::vector<hipEvent_t> e0, e1, h0, h1;
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -898,7 +905,7 @@ static int step_loop_res(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   c->mur_pre_step = -1;   // (the Mur state arrays are not kept by the resident kernel: the next two-launch timestep runs its own pre pass)
   if (pe) pe->launches = launches;
   HIPCK(c, hipGetLastError());
-  return FDTD_OK;
+  return launch_status(c);
 }
 
 static void p2p_prime_if_needed(fdtd_ctx* c);
@@ -937,7 +944,7 @@ static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   }
   if (pe) pe->launches = launches;
   HIPCK(c, hipGetLastError());
-  return FDTD_OK;
+  return launch_status(c);
 }
 // after the stream has drained: did a flag wait of the wavefront schedule time out?
 static int wf_check(fdtd_ctx* c) {
@@ -983,7 +990,7 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   }
   if (fused && nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);   // flush the last step's I-probes
   HIPCK(c, hipGetLastError());
-  return FDTD_OK;
+  return launch_status(c);
 }
 
 // P2P mailbox transport: the halos travel inside the update kernels, so a step is two launches on ONE stream —
@@ -1024,7 +1031,7 @@ static int step_loop_p2p(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   }
   if (nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);   // flush the last step's I-probes
   HIPCK(c, hipGetLastError());
-  return FDTD_OK;
+  return launch_status(c);
 }
 
 int fdtd_run(fdtd_ctx* c, int nsteps) {
@@ -1142,7 +1149,7 @@ int fdtd_half_step(fdtd_ctx* c, int phase) {
   } else return fdtd_fail(c, FDTD_E_ARG, "bad phase");
   HIPCK(c, hipGetLastError());
   HIPCK(c, hipStreamSynchronize(s));
-  return FDTD_OK;
+  return launch_status(c);
 }
 
 static hipError_t plane_d2h(const fdtd_ctx* c, float* host, const float* dev) {
@@ -1557,6 +1564,7 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
       int rc = p2p_check(c);
       if (rc) return rc;
       if ((rc = wf_check(c))) return rc;
+      if ((rc = launch_status(c))) return rc;
     }
     return FDTD_OK;
   }
@@ -1587,6 +1595,7 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
     HIPCK(c, hipSetDevice(c->d.device));
     HIPCK(c, hipStreamSynchronize(c->stream));
     HIPCK(c, hipStreamSynchronize(c->comm_stream));
+    if (int rc = launch_status(c)) return rc;
   }
   return FDTD_OK;
 }

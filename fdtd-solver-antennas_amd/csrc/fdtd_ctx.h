@@ -233,6 +233,7 @@ struct fdtd_ctx {
   fdtd_ctx* link_hi = nullptr;
   bool haloE_issued = false, haloH_issued = false;
   bool tables_dirty = true;
+  int launch_failed = 0;         // a main-kernel launch the runtime refused (launch_main): the step loop returns this code, message in err
   hipEvent_t kev0 = nullptr, kev1 = nullptr;   // profiled run: start / stop events the next main launch carries
   std::string err;
 };
@@ -264,6 +265,7 @@ void launch_dft(fdtd_ctx* c, int kind, long long step, hipStream_t s);   // runn
 void launch_rec_dft(const float* rec, long npts, int ns, int nfreq, const double* d_tw, double* d_out, hipStream_t s);
 void launch_energy(fdtd_ctx* c, hipStream_t s);
 void choose_tiling(fdtd_ctx* c);
+int chip_cus(int device);        // compute units of the (logical) device, from the runtime
 // resident.hip: small grids resident in registers for the length of a launch
 bool res_possible(fdtd_ctx* c, const char** why);
 int res_prepare(fdtd_ctx* c, int max_chunk);

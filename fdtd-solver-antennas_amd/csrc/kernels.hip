@@ -30,6 +30,7 @@
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <cmath>
+#include <map>
 #include <vector>
 
 #include "kernel_common.hpp"
@@ -1035,45 +1036,94 @@ int xcd_adapt(fdtd_ctx* c) {
   return FDTD_OK;
 }
 
-// Occupancy cap without recompiling (experiments): dynamic LDS padding so that at most `cap` blocks fit the CU's
-// 160 KiB (0 = no cap).  Measured (profiles/r01/occupancy_cap_sweep.txt): throughput falls monotonically with the cap
-// on cache-resident and HBM-resident grids alike, so the default is no cap.
-static unsigned lds_pad(int cap, unsigned static_bytes) {
+// What the launchers need to know about the chip, asked of the runtime once per device (round 3 hard-coded 256 CUs and 160 KiB: wrong on a
+// partitioned gfx950 — CPX / DPX logical devices of 32 / 128 CUs — and one __shared__ edit away from an over-sized launch).
+struct ChipInfo { int cus = 256; unsigned lds_cu = 163840u, lds_block = 65536u; bool ok = false; };
+static const ChipInfo& chip_info(int device) {
+  static ChipInfo info[64];
+  ChipInfo& ci = info[device & 63];
+  if (!ci.ok) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      ci.cus = std::max(1, prop.multiProcessorCount);
+      ci.lds_cu = (unsigned)prop.maxSharedMemoryPerMultiProcessor;
+      ci.lds_block = (unsigned)prop.sharedMemPerBlock;
+      if (ci.lds_cu < ci.lds_block) ci.lds_cu = ci.lds_block;
+    } else (void)hipGetLastError();
+    ci.ok = true;
+  }
+  return ci;
+}
+int chip_cus(int device) { return chip_info(device).cus; }
+// static LDS of a kernel as compiled (hipFuncGetAttributes), cached per kernel; ~0u: the runtime would not say
+static unsigned static_lds_of(const void* fn) {
+  static std::map<const void*, unsigned> cache;
+  auto it = cache.find(fn);
+  if (it != cache.end()) return it->second;
+  hipFuncAttributes at;
+  unsigned v = ~0u;
+  if (hipFuncGetAttributes(&at, fn) == hipSuccess) v = (unsigned)at.sharedSizeBytes; else (void)hipGetLastError();
+  cache[fn] = v;
+  return v;
+}
+// Occupancy cap without recompiling: dynamic LDS padding so that at most `cap` blocks of THIS kernel fit a CU (0 = no cap).  Sized from the
+// kernel's own static LDS and the device's limits: `cap` blocks fit, cap + 1 do not, static + dynamic never exceeds what one block may
+// have — where that cannot be had (or the runtime does not tell) there is no padding: a cap is a speed knob, never a reason to fail.
+static unsigned lds_pad(const fdtd_ctx* c, const void* fn, int cap, unsigned dyn_base) {
   if (cap <= 0) return 0;
-  // (1 KiB of slack: static_bytes is an upper estimate of what the kernel declares; static + dynamic must stay within 160 KiB)
-  const unsigned total = ((163840u - 1024u) / (unsigned)cap) & ~1023u;
-  return total > static_bytes ? total - static_bytes : 0;
+  const unsigned st = static_lds_of(fn);
+  if (st == ~0u) return 0;
+  const ChipInfo& ci = chip_info(c->d.device);
+  unsigned per = (ci.lds_cu / (unsigned)cap) & ~1023u;     // a block's LDS so that `cap` of them fill the CU
+  if (per > ci.lds_block) per = ci.lds_block & ~1023u;
+  const unsigned used = st + dyn_base;
+  return per > used ? per - used : 0;
 }
 
-// Main-kernel launch; in a profiled run (fdtd_run_profiled) the launch carries start / stop events that receive the
-// dispatch's own begin and end timestamps.
+// Main-kernel launch with `dyn` bytes of dynamic LDS (+ the padding of an occupancy cap); in a profiled run (fdtd_run_profiled) the launch
+// carries start / stop events that receive the dispatch's own begin and end timestamps.  A launch the runtime refuses is recorded in the
+// context (the step loops return it as FDTD_E_DEVICE): the header promises error codes, never an abort.
 template <typename K, typename... A>
-static void launch_main(fdtd_ctx* c, K kern, dim3 grid, unsigned lds, hipStream_t s, A... args) {
+static void launch_main(fdtd_ctx* c, K kern, dim3 grid, unsigned dyn, int cap, hipStream_t s, A... args) {
+  const unsigned lds = dyn + lds_pad(c, reinterpret_cast<const void*>(kern), cap, dyn);
+  const ChipInfo& ci = chip_info(c->d.device);
+  const unsigned st = static_lds_of(reinterpret_cast<const void*>(kern));
+  if (st != ~0u && st + lds > ci.lds_block) {
+    if (!c->launch_failed) fdtd_fail(c, FDTD_E_UNSUPPORTED, "kernel launch needs %u bytes of LDS per workgroup, the device allows %u", st + lds, ci.lds_block);
+    c->launch_failed = FDTD_E_UNSUPPORTED;
+    return;
+  }
   if (c->kev0) hipExtLaunchKernelGGL(kern, grid, dim3(FDTD_BLOCK), lds, s, c->kev0, c->kev1, 0, args...);
   else hipLaunchKernelGGL(kern, grid, dim3(FDTD_BLOCK), lds, s, args...);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess && !c->launch_failed) {
+    fdtd_fail(c, FDTD_E_DEVICE, "kernel launch failed: %s (grid %u, %u bytes of dynamic LDS)", hipGetErrorString(e), grid.x, lds);
+    c->launch_failed = FDTD_E_DEVICE;
+  }
 }
 
 template <int COEF, bool PML>
 static void launch_E2(fdtd_ctx* c, int k_begin, int nkr, long long step, bool fused, int extra, hipStream_t s) {
   const unsigned lut_bytes = (unsigned)(c->raw_op ? 0 : (c->p.lut_n + 1) / 2) * 16u;   // dynamic LDS: the coefficient table, whole 16-byte LDS-DMA pieces
-  const unsigned pad = lut_bytes + lds_pad(c->occ_e, (PML && FDTD_PSI_STAGE ? 20480u : 4608u) + lut_bytes);
+  const unsigned pad = lut_bytes;
+  const int cap = c->occ_e;
   if (c->p.p2p) {   // whole slab in one launch: [bottom plane (halo-dependent)] [planes 1.. in eight XCD shares] [probe block] (decode_block_p2p)
     const FastDiv fd_ps = make_fastdiv((unsigned)(nkr - 1) * (unsigned)c->p.nbs);
     const unsigned nb_main = (unsigned)c->p.nstrips * (unsigned)(nkr - 1) * (unsigned)c->p.nbs;
     set_xcd_shares(c, 1, nkr - 1);
     const dim3 grid(c->p.xgrid + (unsigned)(c->p.nstrips * c->p.nbs) + (unsigned)extra);
-    launch_main(c, k_update_E<COEF, PML, true, true>, grid, pad, s, c->p, 0, fd_ps, step, extra, nb_main);
+    launch_main(c, k_update_E<COEF, PML, true, true>, grid, pad, cap, s, c->p, 0, fd_ps, step, extra, nb_main);
     return;
   }
   set_xcd_shares(c, k_begin, nkr);
   const dim3 grid(c->p.xgrid + (unsigned)extra);
   const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
   if (fused && c->mur_post_in_E) {
-    launch_main(c, k_update_E_mur<COEF, PML>, grid, pad, s, c->p, k_begin, fd_ps, step, extra, c->h_mur);
+    launch_main(c, k_update_E_mur<COEF, PML>, grid, pad, cap, s, c->p, k_begin, fd_ps, step, extra, c->h_mur);
     return;
   }
-  if (fused) launch_main(c, k_update_E<COEF, PML, true, false>, grid, pad, s, c->p, k_begin, fd_ps, step, extra, 0u);
-  else launch_main(c, k_update_E<COEF, PML, false, false>, grid, pad, s, c->p, k_begin, fd_ps, step, 0, 0u);
+  if (fused) launch_main(c, k_update_E<COEF, PML, true, false>, grid, pad, cap, s, c->p, k_begin, fd_ps, step, extra, 0u);
+  else launch_main(c, k_update_E<COEF, PML, false, false>, grid, pad, cap, s, c->p, k_begin, fd_ps, step, 0, 0u);
 }
 
 void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool fused, bool probe_block, hipStream_t s) {
@@ -1094,19 +1144,20 @@ void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool f
 
 template <bool RAW, bool PML>
 static void launch_H2(fdtd_ctx* c, int k_begin, int nkr, long long step, int extra, hipStream_t s) {
-  const unsigned pad = lds_pad(c->occ_h, PML && FDTD_PSI_STAGE ? 18432u : 2560u);
+  const unsigned pad = 0u;
+  const int cap = c->occ_h;
   if (c->p.p2p) {
     const FastDiv fd_ps = make_fastdiv((unsigned)(nkr - 1) * (unsigned)c->p.nbs);
     const unsigned nb_main = (unsigned)c->p.nstrips * (unsigned)(nkr - 1) * (unsigned)c->p.nbs;
     set_xcd_shares(c, 0, nkr - 1);
     const dim3 grid(c->p.xgrid + (unsigned)(c->p.nstrips * c->p.nbs) + (unsigned)extra);
-    launch_main(c, k_update_H<RAW, PML, true>, grid, pad, s, c->p, 0, fd_ps, step, extra, nb_main);
+    launch_main(c, k_update_H<RAW, PML, true>, grid, pad, cap, s, c->p, 0, fd_ps, step, extra, nb_main);
     return;
   }
   set_xcd_shares(c, k_begin, nkr);
   const dim3 grid(c->p.xgrid + (unsigned)extra);
   const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
-  launch_main(c, k_update_H<RAW, PML, false>, grid, pad, s, c->p, k_begin, fd_ps, step, extra, 0u);
+  launch_main(c, k_update_H<RAW, PML, false>, grid, pad, cap, s, c->p, k_begin, fd_ps, step, extra, 0u);
 }
 
 void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s, bool mur_pre) {
@@ -1137,7 +1188,7 @@ int wf_lag_for(const fdtd_ctx* c) {
   // (300x300x60: 72.5 -> 74.8 Gcells/s, 200x200x40: 56.5 -> 60.3)
   if ((size_t)(c->d.nk + 2) * c->plane * 6 * sizeof(float) <= ((size_t)FDTD_WF_AUTO_MIB << 20)) return c->d.nk;
   const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs, m = (nbp + 7u) / 8u;
-  const unsigned resident = 256u * (unsigned)(c->occ_wf > 0 && c->occ_wf < FDTD_WF_MINBLOCKS ? c->occ_wf : FDTD_WF_MINBLOCKS);
+  const unsigned resident = (unsigned)chip_cus(c->d.device) * (unsigned)(c->occ_wf > 0 && c->occ_wf < FDTD_WF_MINBLOCKS ? c->occ_wf : FDTD_WF_MINBLOCKS);
   return (int)((resident + 16u * m - 1u) / (16u * m)) + 2;
 }
 
@@ -1145,7 +1196,7 @@ template <int COEF, bool PML, bool P2P>
 static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s, int nsteps) {
   const unsigned nbp = (unsigned)c->p.nstrips * (unsigned)c->p.nbs;
   const unsigned lut_bytes = (unsigned)(c->raw_op ? 0 : (c->p.lut_n + 1) / 2) * 16u;
-  const unsigned pad = lut_bytes + lds_pad(c->occ_wf, (PML && FDTD_PSI_STAGE ? 20480u : 4608u) + lut_bytes);
+  const unsigned pad = lut_bytes;
   const int down = (!P2P && c->p.sweep_rev && (step & 1)) ? 1 : 0;
   if (lag >= c->p.nk) {   // all E blocks, then all H blocks (cache-resident slabs: wf_lag_for), each half in eight cost-weighted XCD shares
     set_xcd_shares(c, 0, c->p.nk);
@@ -1162,18 +1213,18 @@ static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s, in
       // 150x150x40 (960 blocks per half-step) 25.6 us per timestep with 7 blocks per CU, 18.3 with 4; 200x200x40 (1600) 24.8 ->
       // 20.9 with 6; 100x100x40 (480) 19.1 -> 13.8 with 2; from 1920 blocks on the cap costs
       // (profiles/r03/occupancy_cap_sweep_multi_timestep_launches.txt).  Resident slots ~ the blocks of one half-step, rounded up:
-      unsigned pad_m = pad;
+      int cap_m = c->occ_wf;
       if (c->occ_wf <= 0) {
-        const double per_cu = (double)nbp * c->p.nk / 256.0;     // blocks of one half-step per CU
+        const double per_cu = (double)nbp * c->p.nk / (double)chip_cus(c->d.device);     // blocks of one half-step per CU
         const int cap = per_cu >= 7.0 ? FDTD_WF_MINBLOCKS : std::min(6, (int)per_cu + 1);
-        if (cap < FDTD_WF_MINBLOCKS) pad_m = lut_bytes + lds_pad(cap, (PML && FDTD_PSI_STAGE ? 20480u : 4608u) + lut_bytes);
+        if (cap < FDTD_WF_MINBLOCKS) cap_m = cap;
       }
       if constexpr (!P2P)
-        launch_main(c, k_step<COEF, PML, false, true>, dim3(per * (unsigned)nsteps), pad_m, s, c->p, step, -1, c->wf_epoch - (unsigned)(nsteps - 1), nbp,
+        launch_main(c, k_step<COEF, PML, false, true>, dim3(per * (unsigned)nsteps), pad, cap_m, s, c->p, step, -1, c->wf_epoch - (unsigned)(nsteps - 1), nbp,
                     make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), 0, 2u * nE, make_fastdiv(per));
       return;
     }
-    launch_main(c, k_step<COEF, PML, P2P>, dim3(2u * nE + (unsigned)c->nprobe), pad, s, c->p, step, -1, c->wf_epoch, nbp,
+    launch_main(c, k_step<COEF, PML, P2P>, dim3(2u * nE + (unsigned)c->nprobe), pad, c->occ_wf, s, c->p, step, -1, c->wf_epoch, nbp,
                 make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), down, 2u * nE, make_fastdiv(1u));
     c->p.xstamp = nullptr;
     return;
@@ -1183,7 +1234,7 @@ static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s, in
   const unsigned nmain = 8u * 2u * m * (unsigned)(c->p.nk + lag);
   const dim3 grid(nmain + (unsigned)c->nprobe);
   c->p.xstamp = nullptr;   // (no calibration in this order: the XCD groups advance in step)
-  launch_main(c, k_step<COEF, PML, P2P>, grid, pad, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m), down, nmain, make_fastdiv(1u));
+  launch_main(c, k_step<COEF, PML, P2P>, grid, pad, c->occ_wf, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m), down, nmain, make_fastdiv(1u));
 }
 template <int COEF, bool PML>
 static void launch_step2(fdtd_ctx* c, long long step, int lag, hipStream_t s, int nsteps) {
