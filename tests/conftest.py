@@ -28,9 +28,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def oracle_lib():
     """The CPU oracle (test infrastructure) — built on demand from oracle/."""
+    odir = os.environ.get("FDTD_ORACLE_DIR")      # the sanitizer builds: oracle/_asan (tools/run_oracle_asan.sh)
+    if odir:
+        return pkg("_capi").bind(ctypes.CDLL(os.path.join(odir, "libfdtd_oracle.so")))
     so = os.path.join(ROOT, "oracle", "libfdtd_oracle.so")
+    so64 = os.path.join(ROOT, "oracle", "libfdtd_oracle_f64.so")
     src = os.path.join(ROOT, "oracle", "fdtd_oracle.c")
-    if not os.path.isfile(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    if not os.path.isfile(so) or not os.path.isfile(so64) or min(os.path.getmtime(so), os.path.getmtime(so64)) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     return pkg("_capi").bind(ctypes.CDLL(so))
 

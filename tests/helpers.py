@@ -38,7 +38,7 @@ STAGE_EMET, STAGE_HMET, STAGE_OVER_VV, STAGE_OVER_M, STAGE_CPML, STAGE_SIGNAL, S
 def load_oracle_f64():
     import ctypes, os
     from conftest import ROOT
-    path = os.path.join(ROOT, "oracle", "libfdtd_oracle_f64.so")
+    path = os.path.join(os.environ.get("FDTD_ORACLE_DIR") or os.path.join(ROOT, "oracle"), "libfdtd_oracle_f64.so")
     lib = pkg("_capi").bind(ctypes.CDLL(path))
     lib.fdtd_oracle_real_bytes.restype = ctypes.c_int
     assert lib.fdtd_oracle_real_bytes() == 8
