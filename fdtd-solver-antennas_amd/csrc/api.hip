@@ -848,10 +848,9 @@ static bool wavefront_active(const fdtd_ctx* c) {
   const size_t blocks = (size_t)c->d.nk * c->p.nstrips * c->p.nbs;   // per sweep
   if (c->d.world == 1) return big || c->have_cpml || blocks >= 3000;
   // Slabs that SHARE a device with a neighbour (several contexts of one process on one GPU, or several ranks on one GPU: the test boxes)
-  // take two launches: a one-launch kernel keeps blocks resident that spin on a neighbour's halo, and with several such kernels on one
-  // chip the spinning blocks can hold every slot while the kernel they wait for cannot get one (six slabs of 1 864 small blocks per
-  // sweep, four of them one-launch: a 10 s halo timeout, found by tests/fuzz_parity.py --slabs).  On its own GPU a slab cannot starve
-  // its neighbour.  (FDTD_FLAG_LOOPBACK: a slab timed ALONE as it runs in an N-GPU job keeps the N-GPU rule.)
+  // take two launches: fewer workgroups that can sit resident waiting for another kernel (p2p_pinned_blocks below: one plane's blocks
+  // instead of three), i.e. the starvation-freedom condition of p2p_shared_device_ok holds for three times as many slabs.  On its own GPU a
+  // slab cannot starve its neighbour.  (FDTD_FLAG_LOOPBACK: a slab timed ALONE as it runs in an N-GPU job keeps the N-GPU rule.)
   if (!(c->d.flags & FDTD_FLAG_LOOPBACK) && (c->link_info[0][7] == 1 || c->link_info[1][7] == 1)) return false;
   // slabs on the mailbox transport: when a sweep is more than one round of resident blocks (an interior north-star slab whose
   // halos go to itself: 20 planes 29.5 -> 25.3 us per step with one launch; 15 planes 23.3 -> 25.4, 8 planes 17.8 -> 19.8)
@@ -908,6 +907,38 @@ static int step_loop_res(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   return launch_status(c);
 }
 
+// ---- slabs on the mailbox transport that share ONE GPU: when can they not starve each other? ------------------------------------------
+// A workgroup that waits for a halo granule spins while it holds its slot on the chip.  The granule is produced by ANOTHER kernel (the
+// neighbour slab's); on the neighbour's own GPU that kernel always finds slots, on a shared GPU it needs slots the spinning workgroups
+// may hold.  PINNED workgroups of a launch = those that can be resident without being able to finish until another KERNEL has run:
+//   two launches per timestep:  the halo plane's blocks (update_E: plane 0, update_H: the top plane): B = nstrips * nbs;
+//   one launch per timestep:    the E blocks of plane 0 (halo from below), the H blocks of plane 0 (they wait for those E blocks' flags), the
+//                               H blocks of the top plane (halo from above) and the probe blocks: 3 B + nprobe.
+// Every other workgroup of a launch depends on nothing outside its launch (or only on flags of EARLIER workgroups of its own launch, which
+// in-order dispatch has made resident before it) and retires.  The producer of a granule is never itself waiting for anything that is still
+// to be submitted: H halo of timestep s - 1 <- the neighbour's H blocks, which wait for MY E halo of s - 1, sent before my launch of s began
+// (same stream); E halo of s <- the neighbour's E blocks of plane 0, which wait for MY H halo of s - 1, likewise sent.  So the chain of waits
+// ends, at the latest at an end slab, in workgroups that need nothing but a slot — and if the pinned workgroups of ALL launches that can be
+// resident together (one per slab on the device: a stream runs one kernel at a time) are fewer than the chip's slots, a slot is always free
+// for them: progress, by induction along the chain.  The recorded timeout (tests/fuzz_parity.py --slabs, seed 7 case 176: six slabs of 199 x 233 x
+// 45 in one-row strips, B = 233; four slabs under one launch, two under two) had 4 * 699 + 2 * 233 = 3262 pinned workgroups against 1792 slots;
+// all-one-launch (4194) violates the bound as well — that it was "gone" there was a handful of lucky runs of an intermittent event, not safety —
+// and two launches everywhere (1398) satisfy it.  The rule is enforced, not assumed: a configuration that violates it is FDTD_E_UNSUPPORTED
+// (the run-time ladders take the next transport; fdtd_link's event-ordered peer copies never spin).
+static unsigned p2p_pinned_blocks(const fdtd_ctx* c, bool one_launch) {
+  const unsigned pb = (unsigned)c->p.nstrips * (unsigned)c->p.nbs;
+  return one_launch ? 3u * pb + (unsigned)c->nprobe : pb;
+}
+static unsigned chip_slots(const fdtd_ctx* c) {   // resident workgroups of the update kernels, at the LOWEST occupancy any variant is compiled for / capped to
+  int per_cu = std::min(FDTD_E_MINBLOCKS, std::min(FDTD_H_MINBLOCKS, FDTD_WF_MINBLOCKS)) - 1;
+  for (int cap : {c->occ_e, c->occ_h, c->occ_wf}) if (cap > 0) per_cu = std::min(per_cu, cap);
+  return (unsigned)chip_cus(c->d.device) * (unsigned)std::max(per_cu, 1);
+}
+static int p2p_shared_device_refuse(fdtd_ctx* c, unsigned pinned, unsigned slabs) {
+  return fdtd_fail(c, FDTD_E_UNSUPPORTED, "p2p transport between slabs that share one GPU: %u slabs could pin %u workgroups waiting for each other's halos and the chip holds %u — not starvation-free; use fewer / thicker strips, FDTD_FLAG_KERNEL_DIRECT, or fdtd_link (event-ordered copies)",
+                   slabs, pinned, chip_slots(c));
+}
+
 static void p2p_prime_if_needed(fdtd_ctx* c);
 static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   HIPCK(c, hipSetDevice(c->d.device));
@@ -949,11 +980,17 @@ static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
 // after the stream has drained: did a flag wait of the wavefront schedule time out?
 static int wf_check(fdtd_ctx* c) {
   if (!c->wf_err) return FDTD_OK;
-  int e = 0;
-  HIPCK(c, hipMemcpy(&e, c->wf_err, sizeof(int), hipMemcpyDeviceToHost));
-  if (e) {
-    hipMemset(c->wf_err, 0, sizeof(int));
-    return fdtd_fail(c, FDTD_E_DEVICE, "wavefront schedule: a block waited more than %.3g s for the flag of an earlier block (dispatch not in order?); the fields of this run are invalid — re-initialise them and select FDTD_FLAG_KERNEL_DIRECT (simulation.Simulation.run does both by itself)", (double)c->p.wf_limit * 1e-8);
+  int e[8] = {};
+  HIPCK(c, hipMemcpy(e, c->wf_err, sizeof(e), hipMemcpyDeviceToHost));
+  if (e[0]) {
+    hipMemset(c->wf_err, 0, sizeof(e));
+    // the record of the first wait that gave up: which flag, what it should have held, what it held
+    char what[160] = "";
+    const int per_plane = c->p.nstrips * c->p.nbs;
+    if (e[5] == 2) snprintf(what, sizeof what, "the 'cells read' word of probe %d", e[1]);
+    else if (per_plane > 0) snprintf(what, sizeof what, "the %s flag of plane %d, strip %d, block %d", e[5] ? "H" : "E", e[1] / per_plane, (e[1] % per_plane) / c->p.nbs, e[1] % c->p.nbs);
+    return fdtd_fail(c, FDTD_E_DEVICE, "wavefront schedule: rank %d, workgroup %d of the launch waited more than %.3g s for %s to reach %u and found %u (dispatch not in order?); the fields of this run are invalid — re-initialise them and select FDTD_FLAG_KERNEL_DIRECT (simulation.Simulation.run does both by itself)",
+                     c->d.rank, e[4], (double)c->p.wf_limit * 1e-8, what, (unsigned)e[2], (unsigned)e[3]);
   }
   return FDTD_OK;
 }
@@ -1023,7 +1060,13 @@ static bool wavefront_active(const fdtd_ctx* c);
 static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe);
 static int step_loop_p2p(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   if (c->any_mur || c->d.nk < 2) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "p2p transport: needs >= 2 planes per slab and no Mur faces");
-  if (wavefront_active(c)) return step_loop_wf(c, nsteps, pe);   // one launch per timestep, halos inside it as well
+  const bool one_launch = wavefront_active(c);
+  // a neighbour's slab on THIS device (ranks sharing a GPU): all `world` slabs may be here, under this slab's schedule — the bound above
+  if (!(c->d.flags & FDTD_FLAG_LOOPBACK) && (c->link_info[0][7] == 1 || c->link_info[1][7] == 1)) {
+    const unsigned pinned = (unsigned)c->d.world * p2p_pinned_blocks(c, one_launch);
+    if (pinned >= chip_slots(c)) return p2p_shared_device_refuse(c, pinned, (unsigned)c->d.world);
+  }
+  if (one_launch) return step_loop_wf(c, nsteps, pe);   // one launch per timestep, halos inside it as well
   for (int n = 0; n < nsteps; ++n) {
     int r;
     if ((r = p2p_enqueue_E(c, pe, n)) || (r = p2p_enqueue_H(c, pe, n))) return r;
@@ -1209,7 +1252,7 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_p2p_zero(float* mbox, const size
   if (ctl && t < (size_t)nctl) __hip_atomic_store(ctl + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-__global__ void k_p2p_clear_err(int* err) { __hip_atomic_store(err, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__global__ void k_p2p_clear_err(int* err) { for (int q = 7; q >= 0; --q) __hip_atomic_store(err + q, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // error word + record
 // zero the halo planes (and, with `ctl`, the 64 control words) of this context's own mailbox, on its stream
 static void p2p_zero(fdtd_ctx* c, bool ctl) {
   const size_t n4 = p2p_floats(c) / 4;      // 16-byte groups of the halo part
@@ -1418,8 +1461,8 @@ int fdtd_p2p_selftest(fdtd_ctx* c, unsigned token) {
   if (token == 0u) return fdtd_fail(c, FDTD_E_ARG, "p2p self-test token must be non-zero");
   HIPCK(c, hipSetDevice(c->d.device));
   unsigned* d_res = nullptr;
-  HIPCK(c, hipMalloc(&d_res, 6 * sizeof(unsigned)));
-  HIPCK(c, hipMemsetAsync(d_res, 0, 6 * sizeof(unsigned), c->stream));   // the context's stream is non-blocking: keep everything on it
+  HIPCK(c, hipMalloc(&d_res, 16 * sizeof(unsigned)));                       // [0..3] results, [4..11] the self-test's own error word + record
+  HIPCK(c, hipMemsetAsync(d_res, 0, 16 * sizeof(unsigned), c->stream));   // the context's stream is non-blocking: keep everything on it
   int* d_err = reinterpret_cast<int*>(d_res + 4);                          // the self-test's own error word (a failed test must not poison the run's)
   const unsigned nb = (unsigned)((c->plane / 4 + FDTD_BLOCK - 1) / FDTD_BLOCK);
   hipLaunchKernelGGL(k_p2p_selftest_post, dim3(nb), dim3(FDTD_BLOCK), 0, c->stream, c->p, token);
@@ -1457,14 +1500,21 @@ int fdtd_p2p_detach(fdtd_ctx* c) {
 }
 
 static int p2p_check(fdtd_ctx* c) {
-  int err = 0;
-  HIPCK(c, hipMemcpy(&err, c->p.p2p_err, sizeof(int), hipMemcpyDeviceToHost));
-  if (err) {
+  int err[8] = {};
+  HIPCK(c, hipMemcpy(err, c->p.p2p_err, sizeof(err), hipMemcpyDeviceToHost));
+  if (err[0]) {
     // reported once: cleared (with a system-scope store, like every access to the mailbox) so that a later run on this
     // context is judged on its own — the fields of THIS run are invalid
     hipLaunchKernelGGL(k_p2p_clear_err, dim3(1), dim3(1), 0, c->stream, c->p.p2p_err);
     hipStreamSynchronize(c->stream);
-    return fdtd_fail(c, FDTD_E_DEVICE, "p2p: a halo wait timed out (neighbour rank not stepping, or peer memory not visible); the fields of this run are invalid");
+    // the record the first wait to give up left (kernel_common.hpp: mb_pull2): who waited, for which tag, and what it found
+    const unsigned who = (unsigned)err[1], want = (unsigned)err[2], seen = (unsigned)err[3];
+    const bool h_half = (who >> 28) & 1u, one_launch = (who >> 29) & 1u;
+    const int from = h_half ? c->d.rank + 1 : c->d.rank - 1;
+    return fdtd_fail(c, FDTD_E_DEVICE, "p2p: a halo wait timed out: rank %d, %s half-step of timestep %u (%s), plane %d, strip %u, block %u, cell group %d awaited tag %u from rank %d and found tag %u (%s) — neighbour rank not stepping, starved of the chip by spinning workgroups, or peer memory not visible; the fields of this run are invalid",
+                     c->d.rank, h_half ? "H" : "E", want - 1u, one_launch ? "one launch per timestep" : "two launches per timestep", h_half ? c->d.nk - 1 : 0,
+                     (who >> 14) & 0x3FFFu, who & 0x3FFFu, err[4], want, from, seen,
+                     seen == 0u ? "nothing ever arrived" : seen < want ? "the neighbour is behind: its halo of an earlier timestep" : "a later timestep: the slot was overwritten before it was read");
   }
   return FDTD_OK;
 }
@@ -1546,6 +1596,12 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
     // below of the PREVIOUS step.  (Bottom rank first timed out in exactly that way.)
     std::vector<char> wf((size_t)n);
     for (int r = 0; r < n; ++r) wf[r] = wavefront_active(ctxs[r]) ? 1 : 0;
+    // slabs of this process that share a device: the starvation-freedom bound (p2p_pinned_blocks), with every slab's own schedule
+    for (int r = 0; r < n; ++r) {
+      unsigned pinned = 0, slabs = 0;
+      for (int q = 0; q < n; ++q) if (ctxs[q]->d.device == ctxs[r]->d.device) { pinned += p2p_pinned_blocks(ctxs[q], wf[q] != 0); ++slabs; }
+      if (slabs > 1 && pinned >= chip_slots(ctxs[r])) return p2p_shared_device_refuse(ctxs[r], pinned, slabs);
+    }
     for (int s = 0; s < nsteps; ++s) {
       int rc;
       for (int r = n - 1; r >= 0; --r) { if ((rc = wf[r] ? step_loop_wf(ctxs[r], 1, nullptr) : p2p_enqueue_E(ctxs[r], nullptr, 0))) return rc; }

@@ -101,8 +101,11 @@ __device__ __forceinline__ void mb_push(float* slot, const unsigned o, const uns
 // pull the two halo components of cell group `o`: load both groups' granules, accept when all eight tags are `tag`; a wave
 // whose neighbour is late loads again (bounded: `limit` ticks of the wall clock, then the error word — never a hang; once
 // the error word is set nobody spins).  Every lane of the wave takes part (lanes beyond the strip pull group 0).
+// A wait that gives up says what it was waiting for: err[0] = 1 (the error word every waiter looks at), and — written by the ONE lane that
+// set it — err[1] = `who` (the caller's code for launch kind / plane / strip / block), err[2] = the tag awaited, err[3] = the tag found
+// instead, err[4] = the group offset.  The host turns the record into the message of fdtd_last_error (api.hip: p2p_check).
 __device__ __forceinline__ void mb_pull2(const float* slot_a, const float* slot_b, const unsigned o, const unsigned tag,
-                                         float4& a, float4& b, int* err, const unsigned long long limit) {
+                                         float4& a, float4& b, int* err, const unsigned long long limit, const unsigned who = 0u) {
   const float* qa = slot_a + 2u * o;
   const float* qb = slot_b + 2u * o;
   v4f_sys a0, a1, b0, b1;
@@ -117,7 +120,16 @@ __device__ __forceinline__ void mb_pull2(const float* slot_a, const float* slot_
     if (round == 0) t0 = wall_clock64();
     __builtin_amdgcn_s_sleep(4);
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-    if ((unsigned long long)wall_clock64() - t0 > limit) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    if ((unsigned long long)wall_clock64() - t0 > limit) {
+      if (!ok && atomicCAS(err, 0, 1) == 0) {   // first to give up: leave the record
+        const unsigned seen = __float_as_uint(a0.y) != tag ? __float_as_uint(a0.y) : __float_as_uint(a0.w) != tag ? __float_as_uint(a0.w) :
+                              __float_as_uint(a1.y) != tag ? __float_as_uint(a1.y) : __float_as_uint(a1.w) != tag ? __float_as_uint(a1.w) :
+                              __float_as_uint(b0.y) != tag ? __float_as_uint(b0.y) : __float_as_uint(b0.w) != tag ? __float_as_uint(b0.w) :
+                              __float_as_uint(b1.y) != tag ? __float_as_uint(b1.y) : __float_as_uint(b1.w);
+        err[1] = (int)who; err[2] = (int)tag; err[3] = (int)seen; err[4] = (int)o;
+      }
+      break;
+    }
   }
   a = make_float4(a0.x, a0.z, a1.x, a1.z);
   b = make_float4(b0.x, b0.z, b1.x, b1.z);
@@ -181,13 +193,23 @@ __device__ __forceinline__ int sload_int(const int* q) {
   asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(q));
   return v;
 }
-// bounded poll of one flag (any lane)
+// bounded poll of one flag (any lane).  The first wait to give up leaves a record behind the error word: wf_err[1] = index of the flag (which
+// table: the pointer tells, wf_err[5]), [2] = the value awaited, [3] = the value found, [4] = the waiting block (blockIdx.x)
 __device__ __forceinline__ void wf_poll(const DevParams& p, const unsigned* f, const unsigned target) {
   const unsigned long long t0 = wall_clock64();
-  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+  unsigned seen;
+  while ((seen = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
     __builtin_amdgcn_s_sleep(2);
     if (__hip_atomic_load(p.wf_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-    if ((unsigned long long)wall_clock64() - t0 > p.wf_limit) { __hip_atomic_store(p.wf_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    if ((unsigned long long)wall_clock64() - t0 > p.wf_limit) {
+      if (atomicCAS(p.wf_err, 0, 1) == 0) {
+        const long de = f - p.wf_flags, dh = f - p.wf_flagsH;
+        const bool is_e = de >= 0 && de < (long)p.nk * p.nstrips * p.nbs;
+        p.wf_err[1] = (int)(is_e ? de : dh); p.wf_err[2] = (int)target; p.wf_err[3] = (int)seen; p.wf_err[4] = (int)blockIdx.x;
+        p.wf_err[5] = is_e ? 0 : (dh >= 0 && dh < (long)p.nk * p.nstrips * p.nbs ? 1 : 2);   // 0: an E block's flag, 1: an H block's, 2: a probe block's
+      }
+      break;
+    }
   }
 }
 // Probe q of step `step` as one of the LAST blocks of the step's launch: wait for the blocks that own its cells (E flags for

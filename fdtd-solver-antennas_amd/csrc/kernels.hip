@@ -181,7 +181,8 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
     psi_stage_issue<MULTI>(p, p.psiE, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
   if (dep_in) {   // H halo of step-1 (tag = step + 1; for step 0 the neighbour's INITIAL top plane, pushed by k_p2p_prime); slot of the parity of the step that produced it
     const float* mb = p.mb_in_H + (size_t)((step + 1) & 1) * 2 * mb_slot_words(p);
-    mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u + p.p2p_tag_bias, ix_km, iy_km, p.p2p_err, p.p2p_limit);
+    mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u + p.p2p_tag_bias, ix_km, iy_km, p.p2p_err, p.p2p_limit,
+             (WF ? 0x20000000u : 0u) | ((unsigned)strip << 14) | (unsigned)pb);   // who: E half-step (bit 28 clear), one-launch schedule (bit 29), strip, block
   }
 
   // component x: d1 along y (of Iz), d2 along z (of Iy); y: d1 along z (Ix), d2 along x (Iz);
@@ -416,7 +417,8 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
   }
   if (dep_in) {   // E halo of this step (tag = step + 1)
     const float* mb = p.mb_in_E + (size_t)(step & 1) * 2 * mb_slot_words(p);
-    mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u + p.p2p_tag_bias, vx_kp, vy_kp, p.p2p_err, p.p2p_limit);
+    mb_pull2(mb, mb + mb_slot_words(p), (unsigned)(j * p.P + i0), (unsigned)step + 1u + p.p2p_tag_bias, vx_kp, vy_kp, p.p2p_err, p.p2p_limit,
+             0x10000000u | (WF ? 0x20000000u : 0u) | ((unsigned)strip << 14) | (unsigned)pb);   // who: H half-step (bit 28)
   }
 
   if (LS) {
@@ -1301,7 +1303,7 @@ int launch_step_wf(fdtd_ctx* c, long long step, hipStream_t s, int nsteps) {
     HIPCK(c, hipMalloc(&c->wf_flagsH, nflags * sizeof(unsigned)));
     HIPCK(c, hipMemsetAsync(c->wf_flagsH, 0, nflags * sizeof(unsigned), s));
     c->wf_prb_dirty = true;
-    if (!c->wf_err) { HIPCK(c, hipMalloc(&c->wf_err, sizeof(int))); HIPCK(c, hipMemsetAsync(c->wf_err, 0, sizeof(int), s)); }
+    if (!c->wf_err) { HIPCK(c, hipMalloc(&c->wf_err, 8 * sizeof(int))); HIPCK(c, hipMemsetAsync(c->wf_err, 0, 8 * sizeof(int), s)); }   // error word + the record of the wait that gave up
     c->wf_nflags = nflags;
     c->wf_epoch = 0;
   }

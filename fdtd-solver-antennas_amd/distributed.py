@@ -56,6 +56,11 @@ class SlabComm:
         self.dist.all_reduce(t)
         return t.cpu().numpy().reshape(a.shape)
 
+    def allreduce_max(self, a: np.ndarray) -> np.ndarray:
+        t = self._to_t(np.asarray(a, np.float64))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.cpu().numpy().reshape(np.shape(a))
+
     def barrier(self):
         """Also the tear-down rule of the p2p transport: every rank must have finished its last run before any rank
         frees its engine (a neighbour's last H half-step still writes into this rank's mailbox)."""

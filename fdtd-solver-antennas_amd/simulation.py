@@ -125,6 +125,7 @@ class RunStats:
     stopped_by_energy: bool = False
     schedule_fallback: Optional[str] = None   # set when the run was repeated under the two-launch schedule (see Simulation.run)
     transports_failed: tuple = ()             # decomposed run: halo transports that set up but failed in the first timesteps (see Simulation.run)
+    transport_failure_reasons: tuple = ()     # ... and what the library said each time
 
 
 class Simulation:
@@ -309,16 +310,30 @@ class Simulation:
                 # Decomposed run, first timesteps: the probe of the halo transport the ranks agreed on.  One that set up (and passed
                 # its self-test) but errors once timesteps depend on it — every halo wait is bounded — sends ALL ranks to the next
                 # transport (p2p -> rccl -> host): new contexts, from the initial state.
-                ok, why = True, ""
+                # What failed decides what happens, and every rank does the same (one all-reduce of a code):
+                #   1  a SCHEDULE error (a flag wait of the one-launch schedule ran out): same transport, two launches per timestep;
+                #   2  a TRANSPORT error (a halo wait ran out, the transport is refused on this topology, an RCCL error): the next transport;
+                #   3  anything else (out of memory, a bad argument, a device fault): raised, on every rank — not papered over.
+                code, why = 0, ""
                 try:
                     e.run(n)
                 except _capi.FdtdError as exc:
-                    ok, why = False, str(exc)
-                if not comm._all_agree(ok):
-                    log(f"[fdtd-hip rank {self.rank}] halo transport {comm.transport_used} failed at run time"
-                        + (f" ({why})" if why else "") + " — every rank takes the next one")
-                    stats.transports_failed += (comm.transport_used,)
-                    comm.skip.add(comm.transport_used)
+                    why = str(exc)
+                    low = why.lower()
+                    code = 1 if "wavefront schedule" in low else 2 if ("p2p" in low or "nccl" in low or "rccl" in low) else 3
+                worst = int(round(float(np.max(comm.allreduce_max(np.array([float(code)]))))))
+                if worst == 3:
+                    raise _capi.FdtdError(why or f"rank {self.rank}: another rank's engine failed in the first timesteps of the decomposed run")
+                if worst:
+                    log(f"[fdtd-hip rank {self.rank}] {'one-launch schedule' if worst == 1 else 'halo transport ' + str(comm.transport_used)} failed at run time"
+                        + (f" ({why})" if why else "") + (" — every rank repeats under two launches per timestep" if worst == 1 else " — every rank takes the next one"))
+                    if worst == 1:
+                        stats.schedule_fallback = why or "another rank's one-launch schedule timed out"
+                        self._build_flags = (self._build_flags & ~_capi.FLAG_KERNEL_MASK) | _capi.FLAG_KERNEL_DIRECT
+                    else:
+                        stats.transports_failed += (comm.transport_used,)
+                        stats.transport_failure_reasons += (why or "failed on another rank",)
+                        comm.skip.add(comm.transport_used)
                     comm.barrier()                  # nobody frees a mailbox a neighbour may still write into
                     e.close()
                     e = self.build(self.lib, rank=self.rank, world=self.world, device=self.device, partition=self.partition,

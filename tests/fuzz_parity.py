@@ -239,6 +239,9 @@ def run_batch(ncases, seed, hip, oracle, only=None, log=print, slabs=False):
             log(f"case {n}: skipped ({exc}) {case}")
             continue
         except _mod("_capi").FdtdError as exc:      # an error from the library (a bounded wait that ran out, ...) is a failing case
+            if "not starvation-free" in str(exc):    # ... except a drawn decomposition the library REFUSES: slabs sharing the test GPU that could pin every workgroup slot
+                log(f"case {n}: refused ({str(exc)[:150]}...) {case}")
+                continue
             log(f"case {n}: FAIL (library error) {case}  -> {exc}")
             failed.append((n, case, [str(exc)]))
             continue

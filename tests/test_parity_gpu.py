@@ -772,8 +772,8 @@ def test_wavefront_schedule_odd_tilings_equal_two_launches(hip_lib, shape, tys, 
 
 def test_kernel_schedule_selection(hip_lib):
     """AUTO: one launch per timestep on single slabs (fdtd_profile.fused) — with all E blocks first on cache-resident grids,
-    with H a few planes behind E beyond the Infinity Cache — except small grids without CPML and Mur scenes; DIRECT never,
-    WAVEFRONT always (and refused with Mur faces)."""
+    with H a few planes behind E beyond the Infinity Cache — except small grids without CPML; small Mur scenes run resident in
+    registers (round 4); DIRECT never, WAVEFRONT always (and refused with Mur faces)."""
     capi = pkg("_capi")
     small = patch_sim(64, 60, 36, nr_ts=40, nf2ff=False)
     assert small.build(hip_lib).run_profiled(4).fused == 1
@@ -781,7 +781,9 @@ def test_kernel_schedule_selection(hip_lib):
     small_pec = patch_sim(64, 60, 36, boundary="PEC", nr_ts=40, nf2ff=False)
     assert small_pec.build(hip_lib).run_profiled(4).fused == 0
     assert small_pec.build(hip_lib, flags=capi.FLAG_KERNEL_WAVEFRONT).run_profiled(4).fused == 1
-    assert patch_sim(64, 60, 36, boundary="MUR", nr_ts=40, nf2ff=False).build(hip_lib).run_profiled(4).fused == 0
+    mur = patch_sim(64, 60, 36, boundary="MUR", nr_ts=40, nf2ff=False)
+    assert mur.build(hip_lib).run_profiled(4).fused == 1          # small Mur scenes: the resident schedule (one launch holds many timesteps)
+    assert mur.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT).run_profiled(4).fused == 0
     big = patch_sim(400, 400, 82, nr_ts=40, nf2ff=False)          # 6 x 84 planes x 640 KB = 323 MB
     assert big.build(hip_lib).run_profiled(4).fused == 1
     assert big.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT).run_profiled(4).fused == 0
