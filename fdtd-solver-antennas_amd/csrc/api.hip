@@ -59,6 +59,9 @@ static hipError_t build_source_lists(const fdtd_ctx* c, int tys, int nstrips, in
   }
   std::vector<int2> rng(lists.size());
   std::vector<int> ids;
+  int most = 0;
+  for (size_t q = 0; q < lists.size(); ++q) most = std::max(most, (int)lists[q].size());
+  const_cast<fdtd_ctx*>(c)->src_max_per_strip_plane = most;
   for (size_t q = 0; q < lists.size(); ++q) {
     rng[q].x = (int)ids.size();
     ids.insert(ids.end(), lists[q].begin(), lists[q].end());
@@ -185,6 +188,7 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   if (getenv("FDTD_MUR_UNFUSED")) c->mur_fuse_post = false;   // experiments: the Mur post pass as a launch of its own
   if (const char* v = getenv("FDTD_WAVEFRONT")) c->wf_mode = atoi(v) ? 1 : 0;
   if (const char* v = getenv("FDTD_WF_LAG")) c->wf_lag = std::max(0, std::min(4096, atoi(v)));
+  if (const char* v = getenv("FDTD_RCCL_INLINE")) c->rccl_inline_mode = atoi(v) ? 1 : 0;  // RCCL halos in stream order on the compute stream (1) / overlapped on the communication stream (0)
   if (const char* v = getenv("FDTD_RESIDENT")) c->res_mode = atoi(v) ? 1 : 0;          // 1: the resident schedule whenever it is possible, 0: never
   if (const char* v = getenv("FDTD_RES_CHUNK")) c->res_chunk = std::max(1, std::min(4096, atoi(v)));
   if (const char* v = getenv("FDTD_WF_MULTI")) c->wf_multi = std::max(1, std::min(4096, atoi(v)));   // timesteps per launch at most (1: one launch per timestep)
@@ -196,6 +200,7 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   if (const char* v = getenv("FDTD_XCD_WY")) c->xw_y = std::max(0.0, std::min(4.0, atof(v)));
   if (const char* v = getenv("FDTD_XCD_WZ")) c->xw_z = std::max(0.0, std::min(4.0, atof(v)));
   if (const char* v = getenv("FDTD_XCD_WYZ")) c->xw_yz = std::max(0.0, std::min(4.0, atof(v)));
+  p.src_dense_ok = 1;
   p.src_rng = nullptr; p.src_ids = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
   p.sig = c->sig; p.nsig = 0;
   p.probes = c->d_probe; p.nprobe = 0; p.max_steps = d->max_steps;
@@ -483,6 +488,12 @@ int fdtd_add_source(fdtd_ctx* c, int n, const int64_t* idx, const int8_t* comp, 
   HIPCK(c, to_device(&c->src_delay, c->h_src_delay));
   HIPCK(c, build_source_lists(c, c->p.tys, c->p.nstrips, &c->src_rng, &c->src_ids));
   c->p.src_rng = c->src_rng; c->p.src_ids = c->src_ids;
+  {   // two sources on one edge?  (then the dense form of body_E, which gives every edge one slot, is not taken)
+    std::vector<long long> key(c->h_src_off.size());
+    for (size_t e = 0; e < key.size(); ++e) key[e] = (long long)c->h_src_off[e] * 4 + c->h_src_comp[e];
+    std::sort(key.begin(), key.end());
+    c->p.src_dense_ok = std::adjacent_find(key.begin(), key.end()) == key.end() ? 1 : 0;
+  }
   c->p.nsrc = c->nsrc; c->p.src_off = c->src_off; c->p.src_comp = c->src_comp; c->p.src_amp = c->src_amp;
   c->p.src_delay = c->src_delay;
   return FDTD_OK;
@@ -645,7 +656,7 @@ static int check_ready(fdtd_ctx* c) {
 // Halo exchange on the communication stream.  which = FDTD_HALO_E_DOWN: Vx,Vy plane 0 -> rank-1, ghost
 // plane nk <- rank+1.  FDTD_HALO_H_UP: Ix,Iy plane nk-1 -> rank+1, ghost plane -1 <- rank-1.
 // (a) RCCL: one grouped ncclSend/ncclRecv per exchange, xGMI peer-to-peer.
-static int exchange_rccl(fdtd_ctx* c, int which) {
+static int exchange_rccl(fdtd_ctx* c, int which, hipStream_t cs) {
   ncclComm_t comm = (ncclComm_t)c->comm;
   const int r = c->d.rank, w = c->d.world;
   // FDTD_FLAG_LOOPBACK (transport self-test on one GPU): both neighbours are this rank itself, in a communicator of 1
@@ -656,21 +667,21 @@ static int exchange_rccl(fdtd_ctx* c, int which) {
   NCCLCK(c, ncclGroupStart());
   if (which == FDTD_HALO_E_DOWN) {
     if (r > 0) {
-      NCCLCK(c, ncclSend(c->p.V[0], cnt, ncclFloat, down, comm, c->comm_stream));
-      NCCLCK(c, ncclSend(c->p.V[1], cnt, ncclFloat, down, comm, c->comm_stream));
+      NCCLCK(c, ncclSend(c->p.V[0], cnt, ncclFloat, down, comm, cs));
+      NCCLCK(c, ncclSend(c->p.V[1], cnt, ncclFloat, down, comm, cs));
     }
     if (r < w - 1) {
-      NCCLCK(c, ncclRecv(c->p.V[0] + c->nloc, cnt, ncclFloat, up, comm, c->comm_stream));
-      NCCLCK(c, ncclRecv(c->p.V[1] + c->nloc, cnt, ncclFloat, up, comm, c->comm_stream));
+      NCCLCK(c, ncclRecv(c->p.V[0] + c->nloc, cnt, ncclFloat, up, comm, cs));
+      NCCLCK(c, ncclRecv(c->p.V[1] + c->nloc, cnt, ncclFloat, up, comm, cs));
     }
   } else {
     if (r < w - 1) {
-      NCCLCK(c, ncclSend(c->p.I[0] + top, cnt, ncclFloat, up, comm, c->comm_stream));
-      NCCLCK(c, ncclSend(c->p.I[1] + top, cnt, ncclFloat, up, comm, c->comm_stream));
+      NCCLCK(c, ncclSend(c->p.I[0] + top, cnt, ncclFloat, up, comm, cs));
+      NCCLCK(c, ncclSend(c->p.I[1] + top, cnt, ncclFloat, up, comm, cs));
     }
     if (r > 0) {
-      NCCLCK(c, ncclRecv(c->p.I[0] - c->plane, cnt, ncclFloat, down, comm, c->comm_stream));
-      NCCLCK(c, ncclRecv(c->p.I[1] - c->plane, cnt, ncclFloat, down, comm, c->comm_stream));
+      NCCLCK(c, ncclRecv(c->p.I[0] - c->plane, cnt, ncclFloat, down, comm, cs));
+      NCCLCK(c, ncclRecv(c->p.I[1] - c->plane, cnt, ncclFloat, down, comm, cs));
     }
   }
   NCCLCK(c, ncclGroupEnd());
@@ -700,12 +711,25 @@ static int exchange_linked(fdtd_ctx* c, int which) {
   return FDTD_OK;
 }
 
+// RCCL exchange INLINE on the compute stream: [E sweep][grouped send/recv][H sweep][grouped send/recv], nothing else.  The overlapped schedule
+// (communication stream, four stream-to-stream event hops per timestep, sweeps split into interior + halo-dependent plane) costs a thin slab
+// 80-85 us per timestep whatever the payload — each hop is 10-20 us of latency, there is nothing of that length to overlap with (an 8-plane
+// north-star slab: 14 us of kernels) — and 8 GPUs deliver less than one (profiles/r01/halo_transport_thin_slab_timing.txt).  In stream order no
+// event is needed at all: the exchange starts when the sweep before it has finished and the next sweep starts when the exchange has.  Taken when
+// a sweep is short (fewer than 4096 blocks of 1024 cells: < ~50 us; larger slabs have sweeps worth overlapping), $FDTD_RCCL_INLINE=0/1 decides.
+static bool rccl_inline(const fdtd_ctx* c) {
+  if (!c->comm) return false;
+  if (c->rccl_inline_mode >= 0) return c->rccl_inline_mode != 0;
+  return (size_t)c->d.nk * c->p.nstrips * c->p.nbs < 4096;
+}
+
 static int exchange(fdtd_ctx* c, int which) {
   HIPCK(c, hipSetDevice(c->d.device));
+  if (rccl_inline(c)) return exchange_rccl(c, which, c->stream);
   // nothing of this exchange may start before this slab's own half-step is complete (it both produces the
   // plane that leaves and is the last reader of the ghost plane that is about to be overwritten)
   HIPCK(c, hipStreamWaitEvent(c->comm_stream, which == FDTD_HALO_E_DOWN ? c->ev_E : c->ev_H, 0));
-  int r = c->comm ? exchange_rccl(c, which) : exchange_linked(c, which);
+  int r = c->comm ? exchange_rccl(c, which, c->comm_stream) : exchange_linked(c, which);
   if (r) return r;
   if (which == FDTD_HALO_E_DOWN) { HIPCK(c, hipEventRecord(c->ev_haloE, c->comm_stream)); c->haloE_pending = true; }
   else { HIPCK(c, hipEventRecord(c->ev_haloH, c->comm_stream)); c->haloH_pending = true; }
@@ -717,6 +741,7 @@ static int exchange(fdtd_ctx* c, int which) {
 // freshly updated voltages of that inner plane BEFORE the sources are added in the unfused order, so only there the
 // order of the two matters.  (The reference's ports sit in the middle of the box.)  Saves two launches per step.
 static bool sources_fusable(const fdtd_ctx* c) {
+  if (!c->p.src_dense_ok && c->src_max_per_strip_plane > FDTD_BLOCK) return false;   // (duplicate edges AND more than the scanning stage holds: k_post)
   if (!c->any_mur) return true;
   const int n[3] = {c->d.nx, c->d.ny, c->d.nz};
   for (int off : c->h_src_off) {
@@ -756,7 +781,8 @@ struct ProfEvents {
 // Split a sweep into "all planes but one" + "the halo-dependent plane" so that the exchange in flight overlaps
 // the first part.  Measured with 8 linked NS slabs on one MI355X the split schedule is the faster one even for
 // 7-plane slabs (220 vs 251 us per step for all eight), so it is the default; FDTD_FLAG_OVERLAP_OFF disables it.
-static bool overlap_split(const fdtd_ctx* c) { return !(c->d.flags & FDTD_FLAG_OVERLAP_OFF); }
+static bool rccl_inline(const fdtd_ctx* c);
+static bool overlap_split(const fdtd_ctx* c) { return !(c->d.flags & FDTD_FLAG_OVERLAP_OFF) && !rccl_inline(c); }
 
 static int phase_E(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
   HIPCK(c, hipSetDevice(c->d.device));
@@ -790,7 +816,7 @@ static int phase_E(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
   launch_mur(c, 2, s);
   if (!fused) launch_post(c, FDTD_KIND_V, step, true, s);
   launch_dft(c, FDTD_KIND_V, step, s);
-  if (multi) HIPCK(c, hipEventRecord(c->ev_E, s));
+  if (multi && !rccl_inline(c)) HIPCK(c, hipEventRecord(c->ev_E, s));
   return FDTD_OK;
 }
 
@@ -819,7 +845,7 @@ static int phase_H(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
   }
   if (!fused) launch_post(c, FDTD_KIND_I, step, false, s);
   launch_dft(c, FDTD_KIND_I, step, s);
-  if (multi) HIPCK(c, hipEventRecord(c->ev_H, s));
+  if (multi && !rccl_inline(c)) HIPCK(c, hipEventRecord(c->ev_H, s));
   return FDTD_OK;
 }
 
@@ -831,7 +857,8 @@ static int p2p_check(fdtd_ctx* c);
 // instead of in HBM); FDTD_FLAG_KERNEL_WAVEFRONT / $FDTD_WAVEFRONT=1 force it, FDTD_FLAG_KERNEL_DIRECT / =0 forbid it.
 static bool wavefront_possible(const fdtd_ctx* c) {
   // (an H block polls at most 64 flags with one wave: 2 * (1 + P4 / 256) + 3 <= 64, i.e. rows of at most 30 720 cells)
-  return (c->d.world == 1 || c->p.p2p) && !c->any_mur && c->d.nk >= 2 && 2 * (1 + c->p.P4 / FDTD_BLOCK) + 3 <= 64;
+  return (c->d.world == 1 || c->p.p2p) && !c->any_mur && c->d.nk >= 2 && 2 * (1 + c->p.P4 / FDTD_BLOCK) + 3 <= 64 &&
+         (c->p.src_dense_ok || c->src_max_per_strip_plane <= FDTD_BLOCK);   // (sources are always fused into k_step)
 }
 static bool wavefront_active(const fdtd_ctx* c) {
   const unsigned sel = c->d.flags & FDTD_FLAG_KERNEL_MASK;
@@ -1060,6 +1087,7 @@ static bool wavefront_active(const fdtd_ctx* c);
 static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe);
 static int step_loop_p2p(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   if (c->any_mur || c->d.nk < 2) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "p2p transport: needs >= 2 planes per slab and no Mur faces");
+  if (!c->p.src_dense_ok && c->src_max_per_strip_plane > FDTD_BLOCK) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "p2p transport: more than %d source edges in one strip-plane with several sources on one edge", FDTD_BLOCK);
   const bool one_launch = wavefront_active(c);
   // a neighbour's slab on THIS device (ranks sharing a GPU): all `world` slabs may be here, under this slab's schedule — the bound above
   if (!(c->d.flags & FDTD_FLAG_LOOPBACK) && (c->link_info[0][7] == 1 || c->link_info[1][7] == 1)) {

@@ -118,6 +118,7 @@ struct DevParams {
   const int2* src_rng;       // [nk][nstrips]: range into src_ids of the sources inside that strip-plane
   const int* src_ids;
   int nsrc; const int* src_off; const int8_t* src_comp; const float* src_amp; const int* src_delay;
+  int src_dense_ok;          // 1: no two sources on one edge — strip-planes with more than SRC_SCAN_MAX sources take the dense form (body_E)
   const float* sig; int nsig;
   const struct DevProbe* probes; int nprobe; int max_steps;
   // Mur "pre" pass of the NEXT step as extra blocks of the update_H launch (it only reads V, which update_H does not write)
@@ -213,6 +214,7 @@ struct fdtd_ctx {
   // excitation
   float* sig = nullptr; int nsig = 0;
   int nsrc = 0; int* src_off = nullptr; int8_t* src_comp = nullptr; float* src_amp = nullptr; int* src_delay = nullptr;
+  int src_max_per_strip_plane = 0;   // most source edges in one strip-plane of the current tiling (scanning path: at most FDTD_BLOCK)
   std::vector<int> h_src_off; std::vector<int8_t> h_src_comp; std::vector<float> h_src_amp; std::vector<int> h_src_delay;
   // probes
   int nprobe = 0; DevProbe probe[FDTD_MAX_PROBES] = {}; DevProbe* d_probe = nullptr;
@@ -229,6 +231,7 @@ struct fdtd_ctx {
   hipEvent_t ev_E = nullptr, ev_H = nullptr, ev_haloE = nullptr, ev_haloH = nullptr;
   bool haloE_pending = false, haloH_pending = false;
   void* comm = nullptr;          // ncclComm_t
+  int rccl_inline_mode = -1;     // RCCL exchange in stream order on the compute stream: -1 auto (short sweeps), 0 never, 1 always; $FDTD_RCCL_INLINE
   fdtd_ctx* link_lo = nullptr;   // in-process neighbours (fdtd_link)
   fdtd_ctx* link_hi = nullptr;
   bool haloE_issued = false, haloH_issued = false;

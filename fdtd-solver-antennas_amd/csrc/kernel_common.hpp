@@ -311,7 +311,9 @@ __device__ __forceinline__ bool decode_thread(const DevParams& p, int strip, int
   return true;
 }
 
-// Soft sources of one strip-plane, staged once per block: (flat offset | comp << 29 is avoided: two arrays)
+// Soft sources of one strip-plane, staged once per block: (flat offset | comp << 29 is avoided: two arrays).  Up to SRC_SCAN_MAX of them every
+// thread scans (apply_staged); a strip-plane with more takes the dense LDS image of body_E.
+constexpr int SRC_SCAN_MAX = 32;
 struct SrcStage { int off[FDTD_BLOCK]; float val[FDTD_BLOCK]; signed char comp[FDTD_BLOCK]; };
 // Fill the stage with sources [begin, begin+n) of the id list (n <= FDTD_BLOCK); value = amp*sig[step-delay] or 0.
 __device__ __forceinline__ void stage_sources(const DevParams& p, const int* ids, int begin, int n, long long step, SrcStage& st) {

@@ -172,10 +172,15 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
   // load: left to the compiler this uniform load sits behind the LDS-DMA statements (asm, "memory"), cannot be proven
   // unclobbered and becomes a vector load + s_waitcnt vmcnt(0) in the middle of the load phase — every wave then waited for
   // all its field loads before it issued the staged psi loads, the second round trip the staging exists to avoid.
+  // A strip-plane with MANY source edges (the reference's multi-patch scene draws lumped ports of 1 350 edges each,
+  // solver_fdtd_openems_microstrip_multi_3d.py:472-541: 5 400 in its 2 x 2 array) takes the DENSE form below: every thread scanning the list cost
+  // that scene 175 us per timestep instead of 21.
   int2 srng = make_int2(0, 0);
+  bool dense = false;
   if (FUSE && p.nsrc > 0) {
     srng = sload_int2(p.src_rng + (k * p.nstrips + strip));
-    if (srng.y > srng.x) stage_sources(p, p.src_ids, srng.x, min(srng.y - srng.x, FDTD_BLOCK), step, s_src);
+    dense = srng.y - srng.x > SRC_SCAN_MAX && p.src_dense_ok;   // (two sources on ONE edge keep the scanning path: it adds them in order)
+    if (srng.y > srng.x && !dense) stage_sources(p, p.src_ids, srng.x, srng.y - srng.x, step, s_src);
   }
   if (PML && FDTD_PSI_STAGE)   // psi of the x / z layers: LDS-DMA right behind the field loads (kernel_common.hpp)
     psi_stage_issue<MULTI>(p, p.psiE, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
@@ -205,9 +210,8 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (!WF && !valid) return;
-  if (!WF || valid) {   // (a wavefront block meets once more, at its flag)
-
+  if (!WF && !dense && !valid) return;   // (a wavefront block meets once more, at its flag; a block with dense sources at their barriers)
+  if (valid) {
   if (PML) {
     if (FDTD_PSI_STAGE) {
       psi_stage_apply<MULTI>(p, p.psiE, 0, s_psi, s_xc, xc_lds, k, j, i0, dx2, dy1, dy2, dz1, dx1, dz2);
@@ -231,11 +235,35 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the coefficient loads of the update below out of the CPML section (registers)
   }
+  }   // valid
+  // Dense sources: the block's cells as an LDS image [component][thread][4 cells] of this timestep's source values (the psi staging area
+  // is free by now).  Every thread clears its own twelve slots, the strip-plane's sources are dealt round over the threads and each
+  // lands in the slot of the cell it excites (those of other blocks of the strip-plane fall outside), every thread adds its slots.
+  // (Edges are distinct: two sources on one edge would overwrite each other here — DevParams::src_dense_ok, set by fdtd_add_source.)
+  float* const s_dense = reinterpret_cast<float*>(s_psi);
+  if (FUSE && dense) {
+    if (PML && FDTD_PSI_STAGE) __syncthreads();   // everybody has read its staged psi
+    float4* const d4 = reinterpret_cast<float4*>(s_dense);
+    d4[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); d4[FDTD_BLOCK + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); d4[2 * FDTD_BLOCK + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int t_first = pb * FDTD_BLOCK;
+    for (int q = srng.x + (int)threadIdx.x; q < srng.y; q += FDTD_BLOCK) {
+      const int e = p.src_ids[q];
+      const int r2 = p.src_off[e] - k * p.plane, sj = r2 / p.P, si = r2 - sj * p.P;
+      const int tl = (sj - strip * p.tys) * p.P4 + (si >> 2) - t_first;
+      if ((unsigned)tl < (unsigned)FDTD_BLOCK) {
+        const long long ts = step - p.src_delay[e];
+        if (ts >= 0 && ts < p.nsig) s_dense[(p.src_comp[e] * FDTD_BLOCK + tl) * 4 + (si & 3)] = p.src_amp[e] * p.sig[ts];
+      }
+    }
+    __syncthreads();
+  }
+  if (valid) {
 
   // One component at a time — coefficients, update, sources, store — with a scheduling fence between the components:
   // left to itself the scheduler interleaves all three (12 LDS table reads, 3 metric float4, 6 coefficient float4 live
   // at once), which costs the variant without CPML branches more registers than its occupancy target has (it spilled).
-  const int nsrc_t = (FUSE && srng.y > srng.x) ? min(srng.y - srng.x, FDTD_BLOCK) : 0;
+  const int nsrc_t = (FUSE && !dense) ? srng.y - srng.x : 0;
   uchar4 cc = make_uchar4(0, 0, 0, 0);
   if (COEF == 2) cc = *reinterpret_cast<const uchar4*>(p.ecls + off);
 #pragma unroll
@@ -260,18 +288,13 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
       b = make_float4(l0.y * (ex.x * m), l1.y * (ex.y * m), l2.y * (ex.z * m), l3.y * (ex.w * m));
     }
     v = upd4(a, v, b, d1, d2);
-    if (FUSE && nsrc_t > 0) {
-      // V += amp * sig[step - delay] on the edges of this strip-plane: the first FDTD_BLOCK from the LDS stage,
-      // any overflow (never seen in the reference's scenes) straight from global memory
-      apply_staged(s_src, nsrc_t, comp, off, v);
-      for (int q = srng.x + FDTD_BLOCK; q < srng.y; ++q) {
-        const int e = p.src_ids[q];
-        const unsigned rel = (unsigned)(p.src_off[e] - off);
-        if (rel < 4u && p.src_comp[e] == comp) {
-          const long long t = step - p.src_delay[e];
-          if (t >= 0 && t < p.nsig) add_elem(v, (int)rel, p.src_amp[e] * p.sig[t]);
-        }
-      }
+    if (FUSE && nsrc_t > 0) apply_staged(s_src, nsrc_t, comp, off, v);   // V += amp * sig[step - delay] on the (few) source edges of this strip-plane
+    if (FUSE && dense) {
+      const float4 a = reinterpret_cast<const float4*>(s_dense)[comp * FDTD_BLOCK + threadIdx.x];
+      if (a.x != 0.f) v.x = v.x + a.x;
+      if (a.y != 0.f) v.y = v.y + a.y;
+      if (a.z != 0.f) v.z = v.z + a.z;
+      if (a.w != 0.f) v.w = v.w + a.w;
     }
     if (WF) sto4_dev(p.V[comp], (unsigned)off, v);
     else sto4s(p.nt, p.V[comp], (unsigned)off, v);
@@ -288,11 +311,11 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
 }
 
 template <int COEF, bool PML, bool FUSE, bool P2P>
-__global__ __launch_bounds__(FDTD_BLOCK, (PML || (COEF == 0 && P2P)) ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const FastDiv fd_ps,
+__global__ __launch_bounds__(FDTD_BLOCK, (PML || P2P) ? FDTD_E_MINBLOCKS - 1 : FDTD_E_MINBLOCKS) void k_update_E(const DevParams p, const int k_begin, const FastDiv fd_ps,
                                                                             const long long step, const int extra, const unsigned nb_main) {
   extern __shared__ float2 s_lut[];   // coefficient table, lut_n entries (dynamic: scenes use a few dozen of the up to 768)
   // CPML psi staging (LDS-DMA, 16 KiB); the probe block borrows it for its reduction
-  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : (FUSE ? FDTD_BLOCK / 2 : 1)];
+  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : (FUSE ? 3 * FDTD_BLOCK : 1)];   // (fused sources: the dense image, 12 KiB)
   __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];   // (b, c, 1/kappa) of the x-layer cells, by psi slot
   double* const s_red = reinterpret_cast<double*>(s_psi);
   __shared__ SrcStage s_src;
@@ -315,7 +338,7 @@ template <int COEF, bool PML>
 __global__ __launch_bounds__(FDTD_BLOCK, 4) void k_update_E_mur(const DevParams p, const int k_begin, const FastDiv fd_ps,
                                                                                 const long long step, const int extra, const MurDev m) {
   extern __shared__ float2 s_lut[];
-  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : FDTD_BLOCK / 2];
+  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : 3 * FDTD_BLOCK];
   __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
   __shared__ SrcStage s_src;
   if (extra && blockIdx.x == gridDim.x - 1) {   // probe block: H-probes of the step just finished
@@ -550,7 +573,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_M
                                                                         const unsigned nbp, const FastDiv fd_2m, const int down, const unsigned nmain,
                                                                         const FastDiv fd_per) {
   extern __shared__ float2 s_lut[];
-  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : FDTD_BLOCK / 2];   // (the probe blocks borrow it for their reduction)
+  __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : 3 * FDTD_BLOCK];   // (the probe blocks borrow it for their reduction; dense sources for their image)
   __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
   __shared__ SrcStage s_src;
   unsigned b = blockIdx.x;

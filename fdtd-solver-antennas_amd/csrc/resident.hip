@@ -129,6 +129,14 @@ __device__ __forceinline__ float4 mur_cand4(const float co, const float4& in_new
                      mur_cand(co, in_new.z, b_old.z, in_old.z), mur_cand(co, in_new.w, b_old.w, in_old.w));
 }
 
+#ifdef FDTD_RES_TRACE   // diagnostic builds only (tools/res_trace.py): per workgroup, wall-clock ticks summed over the timesteps of a launch
+#define RES_TRACE_MAX 1024
+__device__ unsigned long long g_res_trace[RES_TRACE_MAX * 8];   // [block][E wait, E compute, H wait, H compute, launch total, set-up, -, -]
+#define RES_T(var) const unsigned long long var = wall_clock64()
+#else
+#define RES_T(var)
+#endif
+
 // COEF: 0 raw arrays, 1 class byte per edge, 2 one packed class byte per cell (as body_E)
 template <int COEF, bool MUR>
 __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, const ResDev r) {
@@ -141,6 +149,10 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
   __shared__ signed char s_psel[RES_MAX_PRB];
 
   const unsigned b = blockIdx.x, nblocks = gridDim.x;
+#ifdef FDTD_RES_TRACE
+  const unsigned long long tr_begin = wall_clock64();
+  unsigned long long tr_ew = 0, tr_ec = 0, tr_hw = 0, tr_hc = 0, tr_setup = 0;
+#endif
   const int zt = (int)(b / (unsigned)r.nstrips), strip = (int)(b - (unsigned)zt * (unsigned)r.nstrips);
   const int k0 = r.kt[zt], ZT = r.kt[zt + 1] - k0, j0 = r.jt[strip], R = r.jt[strip + 1] - j0;
   const int P4 = p.P4, RP = R * P4, nth = ZT * RP;
@@ -222,7 +234,11 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
     if (upJ) { gx_push(r.gx, gx_slot(nblocks, par, b, GX_JUP, 0), idxJ, tag, iz); gx_push(r.gx, gx_slot(nblocks, par, b, GX_JUP, 1), idxJ, tag, ix); }
   }
 
+#ifdef FDTD_RES_TRACE
+  tr_setup = wall_clock64() - tr_begin;
+#endif
   for (int n = 0; n < r.nsteps; ++n) {
+    RES_T(tr0);
     const long long step = r.step0 + n;
     const unsigned par = (unsigned)n & 1u;
     const unsigned tagI_prev = r.tag0 + 2u * (unsigned)n + 1u;   // I of the previous timestep (or the initial fields)
@@ -247,6 +263,9 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
       gx_pull(r, rs, downK, gx_slot(nblocks, par, b - (unsigned)r.nstrips, GX_KUP, 0), gx_slot(nblocks, par, b - (unsigned)r.nstrips, GX_KUP, 1), idxK,
               downJ, gx_slot(nblocks, par, b - 1u, GX_JUP, 0), gx_slot(nblocks, par, b - 1u, GX_JUP, 1), idxJ, tagI_prev + r.pull_bias,
               ix_km, iy_km, iz_jm, ix_jm);
+#ifdef FDTD_RES_TRACE
+      tr_ew += wall_clock64() - tr0;
+#endif
       // component x: d1 along y (of Iz), d2 along z (of Iy); y: d1 along z (Ix), d2 along x (Iz); z: d1 along x (Iy), d2 along y (Ix)
       const float4 dx1 = sub4(iz, iz_jm), dx2 = sub4(iy, iy_km);
       const float4 dy1 = sub4(ix, ix_km);
@@ -325,6 +344,10 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
     if (rec_on && step % r.every == 0 && step / r.every < r.nsamples && valid) res_record(r, FDTD_KIND_V, step / r.every, k, j, i0, vx, vy, vz);
 
     // ================= H half-step: I <- ii I + iv curl V ====================================================================
+    RES_T(tr2);
+#ifdef FDTD_RES_TRACE
+    tr_ec += tr2 - tr0;
+#endif
     __syncthreads();   // every thread's V of this timestep is in sV
     {
       float4 vy_kp = zero4, vx_kp = zero4, vz_jp = zero4, vx_jp = zero4;
@@ -337,6 +360,9 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
       gx_pull(r, rs, upK, gx_slot(nblocks, par, b + (unsigned)r.nstrips, GX_KDOWN, 0), gx_slot(nblocks, par, b + (unsigned)r.nstrips, GX_KDOWN, 1), idxK,
               upJ, gx_slot(nblocks, par, b + 1u, GX_JDOWN, 0), gx_slot(nblocks, par, b + 1u, GX_JDOWN, 1), idxJ, tagV + r.pull_bias,
               vx_kp, vy_kp, vz_jp, vx_jp);
+#ifdef FDTD_RES_TRACE
+      tr_hw += wall_clock64() - tr2;
+#endif
       const float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);
       const float4 dy1 = sub4(vx, vx_kp);
       const float4 dy2 = make_float4(vz.x - vz.y, vz.y - vz.z, vz.z - vz.w, vz.w - vz_ip);
@@ -364,7 +390,16 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
       r.stage[(size_t)n * r.nslots + s_pslot[q]] = (sel >> 2) == 0 ? f4_elem(ix, e) : ((sel >> 2) == 1 ? f4_elem(iy, e) : f4_elem(iz, e));
     }
     if (rec_on && step % r.every == 0 && step / r.every < r.nsamples && valid) res_record(r, FDTD_KIND_I, step / r.every, k, j, i0, ix, iy, iz);
+#ifdef FDTD_RES_TRACE
+    tr_hc += wall_clock64() - tr2;
+#endif
   }
+#ifdef FDTD_RES_TRACE
+  if (t == 0 && b < RES_TRACE_MAX) {   // (E compute / H compute include their waits: subtract on the host)
+    unsigned long long* q = g_res_trace + 8 * b;
+    q[0] = tr_ew; q[1] = tr_ec; q[2] = tr_hw; q[3] = tr_hc; q[4] = wall_clock64() - tr_begin; q[5] = tr_setup; q[6] = (unsigned long long)r.nsteps;
+  }
+#endif
   if (valid) {
     st4(p.V[0] + off, vx); st4(p.V[1] + off, vy); st4(p.V[2] + off, vz);
     st4(p.I[0] + off, ix); st4(p.I[1] + off, iy); st4(p.I[2] + off, iz);
@@ -574,3 +609,9 @@ int launch_resident(fdtd_ctx* c, long long step, int nsteps, hipStream_t s) {
   HIPCK(c, hipGetLastError());
   return FDTD_OK;
 }
+
+#ifdef FDTD_RES_TRACE
+extern "C" int fdtd_debug_res_trace(unsigned long long* out) {   // diagnostic builds only: the table of the last resident launch
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_res_trace), sizeof(unsigned long long) * RES_TRACE_MAX * 8) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -69,7 +69,7 @@ def _graded_fill(a: float, b: float, left: float, right: float, max_res: float, 
     return a + np.cumsum(cells)[:-1]
 
 
-def merge_close_lines(lines: np.ndarray, min_gap: float, lone: float = 0.125) -> np.ndarray:
+def merge_close_lines(lines: np.ndarray, min_gap: float, lone: float = 0.125, record: Optional[list] = None) -> np.ndarray:
     """A pair of hint lines closer than min_gap AND closer than `lone` x the gaps on either side of it becomes ONE line at its middle (the
     outermost two lines stay where they are).
 
@@ -91,6 +91,8 @@ def merge_close_lines(lines: np.ndarray, min_gap: float, lone: float = 0.125) ->
         if cand.size == 0:
             break
         i = int(cand[np.argmin(d[cand])])
+        if record is not None:
+            record.append((float(a[i]), float(a[i + 1])))
         mid = 0.5 * (a[i] + a[i + 1])
         if i == 0:
             mid = a[0]
@@ -104,13 +106,21 @@ def merge_close_lines(lines: np.ndarray, min_gap: float, lone: float = 0.125) ->
 MERGE_FRACTION = 100.0
 
 
-def smooth_mesh_lines(lines: Iterable[float], max_res: float, ratio: float = 1.5) -> np.ndarray:
-    """The hint lines (isolated pairs closer than max_res / 100 merged: merge_close_lines), plus graded fill-in so that no cell is larger than max_res."""
+def smooth_mesh_lines(lines: Iterable[float], max_res: float, ratio: float = 1.5, merge_fraction: Optional[float] = None,
+                      merged: Optional[list] = None) -> np.ndarray:
+    """The hint lines (isolated pairs closer than max_res / merge_fraction merged: merge_close_lines), plus graded fill-in so that no cell
+    is larger than max_res.  merge_fraction: None = MERGE_FRACTION (100; $FDTD_MESH_MERGE_FRACTION overrides), 0 = keep EVERY hint line, as
+    the toolkit the reference calls does (a deliberate deviation of this package, DESIGN.md: out of scope / deviations).  `merged`: a list
+    that receives the (line, line) pairs that became one line, so that a caller can tell its user that the mesh differs."""
     out = unique_lines(lines)
     if out.size < 2:
         return out
     max_res = float(max_res)
-    out = merge_close_lines(out, max_res / MERGE_FRACTION)
+    if merge_fraction is None:
+        import os
+        merge_fraction = float(os.environ.get("FDTD_MESH_MERGE_FRACTION", MERGE_FRACTION))
+    if merge_fraction > 0:
+        out = merge_close_lines(out, max_res / merge_fraction, record=merged)
     for _ in range(10 * out.size + 1000):
         d = np.diff(out)
         big = np.nonzero(d > max_res * (1 + 1e-9))[0]

@@ -63,6 +63,8 @@ class CSRectGrid:
         self._log = log
         self._unit = 1.0
         self._lines = [[], [], []]
+        self.merge_fraction = None      # mesher.smooth_mesh_lines: None = the package default (100), 0 = keep every hint line as openEMS does
+        self.merged_lines = [[], [], []]   # per axis: the (line, line) pairs SmoothMeshLines merged into one — where this mesh differs from openEMS's
 
     def SetDeltaUnit(self, unit):
         self._unit = float(unit)
@@ -90,7 +92,8 @@ class CSRectGrid:
         self._log.add("SmoothMeshLines", axis=ny if isinstance(ny, str) else "xyz"[ny], max_res=max_res, ratio=ratio)
         axes = range(3) if ny == "all" else [_AX[ny]]
         for a in axes:
-            self._lines[a] = smooth_mesh_lines(self._lines[a], max_res, ratio).tolist()
+            self._lines[a] = smooth_mesh_lines(self._lines[a], max_res, ratio, merge_fraction=self.merge_fraction,
+                                               merged=self.merged_lines[a]).tolist()
 
     def Sort(self, ny="all"):
         for a in (range(3) if ny == "all" else [_AX[ny]]):

@@ -665,7 +665,9 @@ def run_prepared_hip(prepared: FDTDPrepared, *, frequency_hz: float, verbose: in
                      "grid": list(fdtd.sim.grid.shape), "schedule_fallback": getattr(st, "schedule_fallback", None),
                      "halo_transports_failed": list(getattr(st, "transports_failed", ())),
                      "nf2ff_warning": getattr(fdtd.sim, "nf2ff_warning", None),
-                     "excitation_warning": getattr(fdtd.sim, "excitation_warning", None)}
+                     "excitation_warning": getattr(fdtd.sim, "excitation_warning", None),
+                     # hint-line pairs the mesher merged (mesher.merge_close_lines): where this mesh differs from the one openEMS would build
+                     "mesh_lines_merged": {"xyz"[a]: list(m) for a, m in enumerate(fdtd.GetCSX().GetGrid().merged_lines) if m}}
         if verbose:
             print(f"[fdtd-hip] done: {st.steps} steps, {st.mcells_per_s:.0f} MC/s, Dmax {10 * np.log10(Dmax):.2f} dBi", flush=True)
         return out

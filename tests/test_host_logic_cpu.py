@@ -270,3 +270,26 @@ def test_nf2ff_box_on_a_metal_sheet_is_flagged():
     for name in ("C2", "NS"):
         s, caught = build(wl.baseline_workload(name))
         assert s.nf2ff_warning is None and not caught
+
+
+def test_mesher_merge_is_optional_and_reported():
+    """merge_close_lines is a deliberate deviation from the toolkit the reference calls (which keeps every hint line): merge_fraction = 0
+    reproduces its lines, and what was merged is reported so that a user can see that the mesh differs."""
+    m = pkg("mesher")
+    lines = [0.0, 10.0, 10.0000068, 20.0, 30.0]
+    rec = []
+    merged = m.smooth_mesh_lines(lines, 3.4, 1.4, merged=rec)
+    assert rec == [(10.0, 10.0000068)] and np.min(np.diff(merged)) > 1.0
+    kept = m.smooth_mesh_lines(lines, 3.4, 1.4, merge_fraction=0)
+    assert np.isclose(np.min(np.diff(kept)), 6.8e-6) and all(np.any(np.isclose(kept, v, rtol=0, atol=1e-12)) for v in lines)
+    # through the mirrored mesh object: the pairs per axis
+    oa = pkg("openems_api")
+    g = oa.ContinuousStructure().GetGrid()
+    g.AddLine("y", lines)
+    g.SmoothMeshLines("y", 3.4, 1.4)
+    assert g.merged_lines[1] == [(10.0, 10.0000068)] and not g.merged_lines[0]
+    g2 = oa.ContinuousStructure().GetGrid()
+    g2.merge_fraction = 0
+    g2.AddLine("y", lines)
+    g2.SmoothMeshLines("y", 3.4, 1.4)
+    assert not g2.merged_lines[1] and np.isclose(np.min(np.diff(np.sort(g2.GetLines("y")))), 6.8e-6)

@@ -217,8 +217,10 @@ def test_schedule_info_tells_the_schedule(hip_lib):
     s = patch_sim(64, 60, 36, nr_ts=10)
     assert s.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT).schedule_info()["launches_per_timestep"] == 2
     s = patch_sim(48, 44, 30, boundary="MUR", nr_ts=10)
-    info = s.build(hip_lib).schedule_info()
-    assert info["launches_per_timestep"] == 3 and not info["xcd_shares_weighted"]
+    info = s.build(hip_lib).schedule_info()       # small Mur scene: resident in registers (round 4), one launch holds up to 256 timesteps
+    assert info["resident"] and info["launches_per_timestep"] == 1 and info["timesteps_per_launch_max"] == 256
+    info = s.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT).schedule_info()
+    assert info["launches_per_timestep"] == 3 and not info["xcd_shares_weighted"] and not info["resident"]
     s = patch_sim(48, 44, 30, boundary="PEC", nr_ts=10)
     assert s.build(hip_lib).schedule_info()["launches_per_timestep"] == 2     # small grid without CPML: two launches
 

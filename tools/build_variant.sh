@@ -8,7 +8,7 @@ src=/root/repo/fdtd-solver-antennas_amd/csrc
 out=/root/repo/scratch/v/$name
 mkdir -p $out
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-unused-value -Wno-unused-result -w $*"
-for f in api kernels opbuild farfield; do
+for f in api kernels resident opbuild farfield; do
   /opt/rocm/bin/hipcc $FL -I$src -c $src/$f.hip -o $out/$f.o &
 done
 wait
