@@ -33,7 +33,8 @@
 namespace {
 
 constexpr int RES_MAX_SRC = 128;     // soft-source edges one tile can hold (the reference's ports have 4-16)
-constexpr int RES_MAX_PRB = 256;     // probe cells one tile can hold (a lumped port: 4 + 8-16)
+constexpr int RES_MAX_PRB = 256;
+     // probe cells one tile can hold (a lumped port: 4 + 8-16)
 
 struct ResDev {
   int nzt, nstrips;          // z tiles, strips (a workgroup = one z tile x one strip, all of x)
@@ -83,6 +84,8 @@ __device__ __forceinline__ void gx_pull(const ResDev& r, const DevRsrc rs, const
     if (pk) pk = !gx_load(rs, ska, skb, idxK, tag, ka, kb);
     if (pj) pj = !gx_load(rs, sja, sjb, idxJ, tag, ja, jb);
     if (__ballot(pk || pj) == 0ull) break;
+    // (Polling harder or softer changes nothing: pausing between rounds, or probing one 16-byte piece per pair until its tags are there,
+    // left the timestep where it was — profiles/r04/resident_phase_trace.txt.  What a waiting workgroup waits for is the hop itself.)
     if ((round & 31) != 31) continue;
     if (t0 == 0ull) t0 = wall_clock64();
     if (__hip_atomic_load(r.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
@@ -109,6 +112,11 @@ __device__ __forceinline__ void res_record(const ResDev& r, const int kind, cons
 
 // Element e (run-time) of a vector, read / replaced with bit masks: a chain of selects becomes an extractelement / insertelement with a
 // variable index, which the backend serves from SCRATCH — and then keeps all six field vectors of the thread there (112 bytes per lane).
+// Workgroup barrier that orders LDS traffic ONLY: __syncthreads() also drains the wave's outstanding vector-memory operations (vmcnt(0)) —
+// here the write-through halo granules just published, whose acknowledgement takes microseconds and which nobody in this workgroup waits
+// for (a granule validates itself by its tag; the exchange needs no store ordering).  LDS writes before it are visible to LDS reads after it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float f4_elem(const float4& v, const int e) {
   const unsigned m0 = 0u - (unsigned)(e == 0), m1 = 0u - (unsigned)(e == 1), m2 = 0u - (unsigned)(e == 2), m3 = 0u - (unsigned)(e == 3);
   return __uint_as_float((__float_as_uint(v.x) & m0) | (__float_as_uint(v.y) & m1) | (__float_as_uint(v.z) & m2) | (__float_as_uint(v.w) & m3));
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
       const long long ts = step - s_sdel[t];
       s_sval[t] = (ts >= 0 && ts < p.nsig) ? s_samp[t] * p.sig[ts] : 0.f;
     }
-    __syncthreads();   // every thread's I of the previous half-step is in sI
+    lds_barrier();   // every thread's I of the previous half-step is in sI
     {
       float4 iy_km = zero4, ix_km = zero4, iz_jm = zero4, ix_jm = zero4;
       float iz_im = 0.f, iy_im = 0.f;
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
       // snapshots of the freshly updated voltages (what the "post" pass sees: before ANY face is applied), then the candidates of
       // every face this thread's cells lie on, faces in order 0..5: the later face wins on shared edges (k_mur's apply rule)
       sV[0][t] = vx; sV[1][t] = vy; sV[2][t] = vz;
-      __syncthreads();
+      lds_barrier();
       if (valid) {
         if (r.mur_on[0] && g == 0) {                       // x = 0: components y, z of cell 0; inner cell 1 (same thread)
           const float co = r.mur_c[0];
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
           vy = mur_cand4(co, sV[1][t - RP], sO[1][t], sO[1][t - RP]);
         }
       }
-      __syncthreads();   // nobody reads the snapshots any more
+      lds_barrier();   // nobody reads the snapshots any more
     }
     sV[0][t] = vx; sV[1][t] = vy; sV[2][t] = vz;
     if (downK) { gx_push(r.gx, gx_slot(nblocks, par, b, GX_KDOWN, 0), idxK, tagV, vx); gx_push(r.gx, gx_slot(nblocks, par, b, GX_KDOWN, 1), idxK, tagV, vy); }
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
 #ifdef FDTD_RES_TRACE
     tr_ec += tr2 - tr0;
 #endif
-    __syncthreads();   // every thread's V of this timestep is in sV
+    lds_barrier();   // every thread's V of this timestep is in sV
     {
       float4 vy_kp = zero4, vx_kp = zero4, vz_jp = zero4, vx_jp = zero4;
       float vz_ip = 0.f, vy_ip = 0.f;
@@ -487,6 +495,16 @@ bool res_possible(fdtd_ctx* c, const char** why) {
   if (c->any_mur) {
     if ((c->mur[2].on && jt[1] - jt[0] < 2) || (c->mur[3].on && jt[nstrips] - jt[nstrips - 1] < 2)) { *why = "Mur y faces need two rows in the end strips"; return false; }
     if ((c->mur[4].on && kt[1] - kt[0] < 2) || (c->mur[5].on && kt[nzt] - kt[nzt - 1] < 2)) { *why = "Mur z faces need plane pairs (rows of at most 256 cells)"; return false; }
+  }
+  if (!c->h_src_off.empty() || c->nprobe > 0) {   // what a tile's LDS tables hold
+    std::vector<int> nsrc_t((size_t)nzt * nstrips, 0), nprb_t((size_t)nzt * nstrips, 0);
+    auto tile = [&](int off) {
+      const int k = off / c->plane, j = (off - k * c->plane) / c->P;
+      return ((int)(std::upper_bound(kt.begin(), kt.end(), k) - kt.begin()) - 1) * nstrips + (int)(std::upper_bound(jt.begin(), jt.end(), j) - jt.begin()) - 1;
+    };
+    for (int off : c->h_src_off) if (++nsrc_t[(size_t)tile(off)] > RES_MAX_SRC) { *why = "at most 128 source edges per tile"; return false; }
+    for (int q = 0; q < c->nprobe; ++q)
+      for (int off : c->h_prb_off[q]) if (++nprb_t[(size_t)tile(off)] > RES_MAX_PRB) { *why = "at most 256 probe cells per tile"; return false; }
   }
   // every workgroup must be resident at once
   const int variant = (c->raw_op ? 0 : (c->packed_op ? 2 : 1)) * 2 + (c->any_mur ? 1 : 0);

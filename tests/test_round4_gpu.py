@@ -35,3 +35,39 @@ def test_occupancy_caps_run_or_return_an_error_code(hip_lib, monkeypatch, bounda
         assert "LDS" in str(exc) or "launch" in str(exc)
         return
     assert np.array_equal(ref, got)
+
+
+def _wide_port_sim(boundary, nr_ts=200):
+    """The fixed patch scene with a lumped port as WIDE as the reference's multi-patch scene draws them (a box of many cells in x and y:
+    solver_fdtd_openems_microstrip_multi_3d.py:472-541 — 1 350 source edges per port there): hundreds of source edges per strip-plane."""
+    wl, sc, sim = pkg("workloads"), pkg("scene"), pkg("simulation")
+    w = wl.patch_workload("test", nx=72, ny=66, nz=34)
+    ports = [p for p in w.scene.ports]
+    assert len(ports) == 1
+    u = 1e-3
+    w.scene.ports.clear()
+    w.scene.add_lumped_port(1, 50.0, [-20, -12, 0], [14, 12, 1.6], "z", 1.0, priority=5)
+    vox = sc.voxelize(w.scene, w.grid)
+    nsrc = sum(p.src_idx.size for p in vox.ports)
+    assert nsrc > 300, nsrc
+    return sim.Simulation(w.grid, vox, f0=w.f0, fc=w.fc, boundary=boundary, cpml_cells=6, nr_ts=nr_ts, nf2ff_freqs=None)
+
+
+@pytest.mark.parametrize("boundary,flag", [("CPML", "AUTO"), ("CPML", "DIRECT"), ("PEC", "WAVEFRONT"), ("MUR", "DIRECT"), ("MUR", "AUTO")])
+def test_many_source_edges_equal_the_oracle(hip_lib, oracle_lib, boundary, flag):
+    """Strip-planes with more source edges than a thread can scan take the dense LDS image (body_E); MUR AUTO: the resident schedule
+    refuses a tile with more than 128 source edges and AUTO falls back to three launches.  Fields bit for bit against the oracle."""
+    capi = pkg("_capi")
+    flags = {"AUTO": 0, "DIRECT": capi.FLAG_KERNEL_DIRECT, "WAVEFRONT": capi.FLAG_KERNEL_WAVEFRONT}[flag]
+    res = []
+    for lib, fl in ((hip_lib, flags), (oracle_lib, 0)):
+        s = _wide_port_sim(boundary)
+        e = s.build(lib, flags=fl)
+        e.run(120)       # the pulse is on: every source edge adds
+        e.run(80)
+        res.append((s, e))
+    (sh, eh), (so, eo) = res
+    fh, fo = eh.fields(), eo.fields()
+    assert np.abs(fo).max() > 0 and np.array_equal(fh, fo)
+    (uh, ih), (uo, io) = sh.port_series()[0], so.port_series()[0]
+    assert np.abs(uo).max() > 0 and np.allclose(uh, uo, rtol=1e-12, atol=0) and np.allclose(ih, io, rtol=1e-12, atol=1e-300)
