@@ -215,6 +215,14 @@ def main():
                     "rccl_nranks": rec[0]["rccl_nranks"], "per_rank": rec,
                     "rank_time_max_over_mean": round(max(t_rank) / (sum(t_rank) / len(t_rank)), 4),
                     "all_slabs_excited": bool(all(r["slab_max_abs_V"] > 0 for r in rec))}
+        # A transport other than the mailbox has a per-timestep floor that does not depend on the slab: say so next to the number it limits.
+        # (one MI355X, an interior north-star slab whose halos go to itself: profiles/r04/halo_transport_thin_slab_timing.txt)
+        if comm.transport_used == "rccl":
+            coupling["transport_note"] = ("fell back to RCCL send/recv: measured floor 43 us per timestep on a 7-plane slab and 52 us on a 17-plane slab "
+                                          "(exchange in stream order on the compute stream; 85 us with the overlapped schedule) against 19 / 27 us with the "
+                                          "P2P mailbox — thin slabs do not scale on this transport")
+        elif comm.transport_used == "host":
+            coupling["transport_note"] = "fell back to host-copied halos (fdtd_half_step + torch.distributed send/recv): a debugging transport, milliseconds per timestep"
     operator_form, steps_total = sim.operator_form, int(eng.step)
     hbm_point = None
     if rank == 0 and world == 1 and not args.no_hbm_point and args.workload != "C3":
