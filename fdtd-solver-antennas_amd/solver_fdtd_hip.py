@@ -613,6 +613,13 @@ def s11_from_port(port, sim_path, f_center: float, npts: int = 201):
     return f, s11, s11_dB, f_res
 
 
+def _merged_lines(fdtd) -> dict:
+    try:
+        return {"xyz"[a]: list(m) for a, m in enumerate(fdtd.GetCSX().GetGrid().merged_lines) if m}
+    except AttributeError:      # an engine object without this package's mesh (duck-typed FDTD objects)
+        return {}
+
+
 def run_prepared_hip(prepared: FDTDPrepared, *, frequency_hz: float, verbose: int = 1) -> FDTDResult:
     """Time-step on the GPU, then far field at `frequency_hz` on the prepared theta x phi grid in ONE
     transform (the reference loops CalcNF2FF over phi: microstrip_3d.py:224-238)."""
@@ -667,7 +674,7 @@ def run_prepared_hip(prepared: FDTDPrepared, *, frequency_hz: float, verbose: in
                      "nf2ff_warning": getattr(fdtd.sim, "nf2ff_warning", None),
                      "excitation_warning": getattr(fdtd.sim, "excitation_warning", None),
                      # hint-line pairs the mesher merged (mesher.merge_close_lines): where this mesh differs from the one openEMS would build
-                     "mesh_lines_merged": {"xyz"[a]: list(m) for a, m in enumerate(fdtd.GetCSX().GetGrid().merged_lines) if m}}
+                     "mesh_lines_merged": _merged_lines(fdtd)}
         if verbose:
             print(f"[fdtd-hip] done: {st.steps} steps, {st.mcells_per_s:.0f} MC/s, Dmax {10 * np.log10(Dmax):.2f} dBi", flush=True)
         return out

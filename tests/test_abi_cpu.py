@@ -26,7 +26,7 @@ def test_hip_library_exports_abi():
     for s in _declared_symbols():
         assert hasattr(lib, s), s
     capi.bind(lib)
-    assert lib.fdtd_version() == 3
+    assert lib.fdtd_version() == 4
     assert lib.fdtd_backend() == b"hip:gfx950"
 
 
