@@ -884,15 +884,20 @@ static bool wavefront_active(const fdtd_ctx* c) {
   return big || blocks >= 1800;
 }
 
-// The grid resident in registers for the length of a launch (k_resident, resident.hip): small single slabs without CPML layers — the
-// reference GUI's default MUR scenes.  AUTO takes it for every such slab WITH Mur faces (three latency-bound launches per timestep
-// otherwise); FDTD_FLAG_KERNEL_RESIDENT / $FDTD_RESIDENT=1 take it wherever it is possible, DIRECT / WAVEFRONT / $FDTD_RESIDENT=0 never.
+// The grid resident in registers for the length of a launch (k_resident, resident.hip): small single slabs — the reference GUI's default
+// scenes, MUR and PML_8 alike.  FDTD_FLAG_KERNEL_RESIDENT / $FDTD_RESIDENT=1 take it wherever it is possible, DIRECT / WAVEFRONT /
+// $FDTD_RESIDENT=0 never, AUTO as below.
 static bool resident_active(fdtd_ctx* c) {
   const unsigned sel = c->d.flags & FDTD_FLAG_KERNEL_MASK;
   if (sel == FDTD_FLAG_KERNEL_DIRECT || sel == FDTD_FLAG_KERNEL_WAVEFRONT || c->res_mode == 0) return false;
   if (!sources_fusable(c) || !res_possible(c, nullptr)) return false;
   if (sel == FDTD_FLAG_KERNEL_RESIDENT || c->res_mode == 1) return true;
-  return c->any_mur;
+  // Mur faces: whenever it is possible (the alternative is three latency-bound launches per timestep).  PEC / CPML: while the tiles are at most two per
+  // CU — 175 ... 400 tiles step in 4.4 ... 7.3 us against 9.7 ... 19.9 us of the flag-coupled launches (x 2.2 - 3.3); at 640 tiles the hop
+  // latency between loaded CUs has grown so much that the two schedules tie (profiles/r04/resident_vs_multi_small_grids.txt)
+  if (c->any_mur) return true;
+  if (res_prepare(c, c->res_chunk) != FDTD_OK) return false;
+  return c->res.nblocks <= 2 * chip_cus(c->d.device);
 }
 static int res_check(fdtd_ctx* c) {
   if (!c->res.err) return FDTD_OK;

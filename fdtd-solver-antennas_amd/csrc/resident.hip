@@ -146,7 +146,47 @@ __device__ unsigned long long g_res_trace[RES_TRACE_MAX * 8];   // [block][E wai
 #endif
 
 // COEF: 0 raw arrays, 1 class byte per edge, 2 one packed class byte per cell (as body_E)
-template <int COEF, bool MUR>
+// CPML inside the resident kernel: the psi values of a thread's cells — two per component and half-step, only where the cell lies in a layer —
+// live in registers next to the fields (48 VGPRs); the 1-D coefficients (b, c, 1/kappa) of the thread's row / plane / four x-cells are fetched
+// at the top of every half-step (read-only tables, L1 hits, in flight while the halos arrive).  Same operations as psi_stage_apply
+// (kernel_common.hpp): psi <- b psi + c d;  d <- d / kappa + psi, on the difference taken along the layer's axis.
+struct ResPml {
+  bool inx, iny, inz;
+  int ox, oy, oz;        // element offsets of the thread's psi values in the x / y / z psi arrays (psi_off_*)
+};
+template <bool EH>   // E-located (false) / H-located (true) coefficient tables
+__device__ __forceinline__ void res_cpml(const DevParams& p, const ResPml& m, const int k, const int j, const int i0, float4 (&ps)[6],
+                                         float4& dzA, float4& dzB, float4& dxA, float4& dxB, float4& dyA, float4& dyB) {
+  constexpr int eh = EH ? 1 : 0;
+  // ps[0], ps[1]: the z pair (psi[0][1], psi[1][0]); ps[2], ps[3]: the y pair (psi[0][0], psi[2][1]); ps[4], ps[5]: the x pair (psi[1][1], psi[2][0])
+  if (m.inz) {
+    const float b = p.cp[2][eh][0][k], c = p.cp[2][eh][1][k], ik = p.cp[2][eh][2][k];
+    cpml_row4_reg(dzA, ps[0], b, c, ik);
+    cpml_row4_reg(dzB, ps[1], b, c, ik);
+  }
+  if (m.iny) {
+    const float b = p.cp[1][eh][0][j], c = p.cp[1][eh][1][j], ik = p.cp[1][eh][2][j];
+    cpml_row4_reg(dyA, ps[2], b, c, ik);
+    cpml_row4_reg(dyB, ps[3], b, c, ik);
+  }
+  if (m.inx) {
+    const float4 b = ld4(p.cp[0][eh][0] + i0), c = ld4(p.cp[0][eh][1] + i0), ik = ld4(p.cp[0][eh][2] + i0);
+    cpml_x4_apply(dxA, ps[4], b, c, ik);
+    cpml_x4_apply(dxB, ps[5], b, c, ik);
+  }
+}
+__device__ __forceinline__ void res_psi_io(const ResPml& m, float* const (&psi)[3][2], float4 (&ps)[6], const bool store) {
+  float* const arr[6] = {psi[0][1], psi[1][0], psi[0][0], psi[2][1], psi[1][1], psi[2][0]};
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const bool in = q < 2 ? m.inz : (q < 4 ? m.iny : m.inx);
+    const int o = q < 2 ? m.oz : (q < 4 ? m.oy : m.ox);
+    if (!in) { if (!store) ps[q] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+    if (store) st4(arr[q] + o, ps[q]); else ps[q] = ld4(arr[q] + o);
+  }
+}
+
+template <int COEF, bool MUR, bool PML>
 __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, const ResDev r) {
   __shared__ float4 sV[3][FDTD_BLOCK], sI[3][FDTD_BLOCK];
   __shared__ float4 sO[MUR ? 3 : 1][MUR ? FDTD_BLOCK : 1];
@@ -202,6 +242,15 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
         ha[comp] = make_float4(1.f, 1.f, 1.f, 1.f);   // (unused: ii = 1, I + t == fmaf(1, I, t) exactly)
       }
     }
+  }
+  ResPml pm{};
+  float4 psE[6], psH[6];   // (dead without PML)
+  if constexpr (PML) {
+    const int ox = psi_off_x(p, k, j, i0), oy = psi_off_y(p, k, j, i0), oz = psi_off_z(p, k, j, i0);
+    pm.inx = valid && ox >= 0; pm.iny = valid && oy >= 0; pm.inz = valid && oz >= 0;
+    pm.ox = ox; pm.oy = oy; pm.oz = oz;
+    res_psi_io(pm, p.psiE, psE, false);
+    res_psi_io(pm, p.psiH, psH, false);
   }
   // soft sources of this tile -> LDS (thread, component * 4 + element, amplitude, delay), in list order
   const int2 srng = r.src_rng[b];
@@ -275,11 +324,12 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
       tr_ew += wall_clock64() - tr0;
 #endif
       // component x: d1 along y (of Iz), d2 along z (of Iy); y: d1 along z (Ix), d2 along x (Iz); z: d1 along x (Iy), d2 along y (Ix)
-      const float4 dx1 = sub4(iz, iz_jm), dx2 = sub4(iy, iy_km);
-      const float4 dy1 = sub4(ix, ix_km);
-      const float4 dy2 = make_float4(iz.x - iz_im, iz.y - iz.x, iz.z - iz.y, iz.w - iz.z);
-      const float4 dz1 = make_float4(iy.x - iy_im, iy.y - iy.x, iy.z - iy.y, iy.w - iy.z);
-      const float4 dz2 = sub4(ix, ix_jm);
+      float4 dx1 = sub4(iz, iz_jm), dx2 = sub4(iy, iy_km);
+      float4 dy1 = sub4(ix, ix_km);
+      float4 dy2 = make_float4(iz.x - iz_im, iz.y - iz.x, iz.z - iz.y, iz.w - iz.z);
+      float4 dz1 = make_float4(iy.x - iy_im, iy.y - iy.x, iy.z - iy.y, iy.w - iy.z);
+      float4 dz2 = sub4(ix, ix_jm);
+      if constexpr (PML) res_cpml<false>(p, pm, k, j, i0, psE, dx2, dy1, dy2, dz1, dx1, dz2);
       if (MUR) { sO[0][t] = vx; sO[1][t] = vy; sO[2][t] = vz; }   // the voltages the Mur "pre" pass sees
       vx = upd4(ea[0], vx, eb[0], dx1, dx2);
       vy = upd4(ea[1], vy, eb[1], dy1, dy2);
@@ -371,11 +421,12 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
 #ifdef FDTD_RES_TRACE
       tr_hw += wall_clock64() - tr2;
 #endif
-      const float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);
-      const float4 dy1 = sub4(vx, vx_kp);
-      const float4 dy2 = make_float4(vz.x - vz.y, vz.y - vz.z, vz.z - vz.w, vz.w - vz_ip);
-      const float4 dz1 = make_float4(vy.x - vy.y, vy.y - vy.z, vy.z - vy.w, vy.w - vy_ip);
-      const float4 dz2 = sub4(vx, vx_jp);
+      float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);
+      float4 dy1 = sub4(vx, vx_kp);
+      float4 dy2 = make_float4(vz.x - vz.y, vz.y - vz.z, vz.z - vz.w, vz.w - vz_ip);
+      float4 dz1 = make_float4(vy.x - vy.y, vy.y - vy.z, vy.z - vy.w, vy.w - vy_ip);
+      float4 dz2 = sub4(vx, vx_jp);
+      if constexpr (PML) res_cpml<true>(p, pm, k, j, i0, psH, dx2, dy1, dy2, dz1, dx1, dz2);
       if (COEF == 0) {
         ix = upd4(ha[0], ix, hb[0], dx1, dx2);
         iy = upd4(ha[1], iy, hb[1], dy1, dy2);
@@ -408,6 +459,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
     q[0] = tr_ew; q[1] = tr_ec; q[2] = tr_hw; q[3] = tr_hc; q[4] = wall_clock64() - tr_begin; q[5] = tr_setup; q[6] = (unsigned long long)r.nsteps;
   }
 #endif
+  if constexpr (PML) { res_psi_io(pm, p.psiE, psE, true); res_psi_io(pm, p.psiH, psH, true); }
   if (valid) {
     st4(p.V[0] + off, vx); st4(p.V[1] + off, vy); st4(p.V[2] + off, vz);
     st4(p.I[0] + off, ix); st4(p.I[1] + off, iy); st4(p.I[2] + off, iz);
@@ -442,12 +494,15 @@ hipError_t res_upload(T** dst, const std::vector<T>& v) {
   return e;
 }
 
-template <int COEF, bool MUR>
-const void* res_kernel() { return reinterpret_cast<const void*>(&k_resident<COEF, MUR>); }
+template <int COEF, bool MUR, bool PML>
+const void* res_kernel() { return reinterpret_cast<const void*>(&k_resident<COEF, MUR, PML>); }
+template <int COEF>
+const void* res_kernel_c(bool mur, bool pml) {
+  return mur ? (pml ? res_kernel<COEF, true, true>() : res_kernel<COEF, true, false>()) : (pml ? res_kernel<COEF, false, true>() : res_kernel<COEF, false, false>());
+}
 const void* res_kernel_of(const fdtd_ctx* c) {
   const int coef = c->raw_op ? 0 : (c->packed_op ? 2 : 1);
-  if (c->any_mur) return coef == 0 ? res_kernel<0, true>() : coef == 1 ? res_kernel<1, true>() : res_kernel<2, true>();
-  return coef == 0 ? res_kernel<0, false>() : coef == 1 ? res_kernel<1, false>() : res_kernel<2, false>();
+  return coef == 0 ? res_kernel_c<0>(c->any_mur, c->have_cpml) : coef == 1 ? res_kernel_c<1>(c->any_mur, c->have_cpml) : res_kernel_c<2>(c->any_mur, c->have_cpml);
 }
 
 }  // namespace
@@ -487,7 +542,6 @@ bool res_possible(fdtd_ctx* c, const char** why) {
   const char* dummy; if (!why) why = &dummy;
   *why = w_ok;
   if (c->d.world != 1 || c->p.p2p) { *why = "single slab only"; return false; }
-  if (c->have_cpml) { *why = "no CPML layers (PEC / Mur faces)"; return false; }
   if (c->d.nx < 6 || c->d.ny < 5 || c->d.nk < 5) { *why = "at least 6 x 5 x 5 nodes"; return false; }
   std::vector<int> kt, jt;
   if (!res_tiling(c, kt, jt)) { *why = "rows of at most 1024 cells"; return false; }
@@ -507,7 +561,7 @@ bool res_possible(fdtd_ctx* c, const char** why) {
       for (int off : c->h_prb_off[q]) if (++nprb_t[(size_t)tile(off)] > RES_MAX_PRB) { *why = "at most 256 probe cells per tile"; return false; }
   }
   // every workgroup must be resident at once
-  const int variant = (c->raw_op ? 0 : (c->packed_op ? 2 : 1)) * 2 + (c->any_mur ? 1 : 0);
+  const int variant = ((c->raw_op ? 0 : (c->packed_op ? 2 : 1)) * 2 + (c->any_mur ? 1 : 0)) * 2 + (c->have_cpml ? 1 : 0);
   if (c->res.capacity < 0 || c->res.capacity_variant != variant) {
     c->res.capacity_variant = variant;
     int per_cu = 0, dev = c->d.device;
@@ -613,13 +667,18 @@ int launch_resident(fdtd_ctx* c, long long step, int nsteps, hipStream_t s) {
   h.tag += 2u * (unsigned)nsteps + 4u;
   const dim3 grid((unsigned)h.nblocks), block(FDTD_BLOCK);
   const int coef = c->raw_op ? 0 : (c->packed_op ? 2 : 1);
-#define RES_LAUNCH(CO, MU)                                                                                          \
-  do {                                                                                                              \
-    if (c->kev0) hipExtLaunchKernelGGL((k_resident<CO, MU>), grid, block, 0, s, c->kev0, c->kev1, 0, c->p, r);      \
-    else hipLaunchKernelGGL((k_resident<CO, MU>), grid, block, 0, s, c->p, r);                                      \
+#define RES_LAUNCH(CO, MU, PM)                                                                                          \
+  do {                                                                                                                  \
+    if (c->kev0) hipExtLaunchKernelGGL((k_resident<CO, MU, PM>), grid, block, 0, s, c->kev0, c->kev1, 0, c->p, r);      \
+    else hipLaunchKernelGGL((k_resident<CO, MU, PM>), grid, block, 0, s, c->p, r);                                      \
   } while (0)
-  if (c->any_mur) { if (coef == 0) RES_LAUNCH(0, true); else if (coef == 1) RES_LAUNCH(1, true); else RES_LAUNCH(2, true); }
-  else { if (coef == 0) RES_LAUNCH(0, false); else if (coef == 1) RES_LAUNCH(1, false); else RES_LAUNCH(2, false); }
+#define RES_LAUNCH_C(CO)                                                                                                \
+  do {                                                                                                                  \
+    if (c->any_mur) { if (c->have_cpml) RES_LAUNCH(CO, true, true); else RES_LAUNCH(CO, true, false); }                 \
+    else { if (c->have_cpml) RES_LAUNCH(CO, false, true); else RES_LAUNCH(CO, false, false); }                          \
+  } while (0)
+  if (coef == 0) RES_LAUNCH_C(0); else if (coef == 1) RES_LAUNCH_C(1); else RES_LAUNCH_C(2);
+#undef RES_LAUNCH_C
 #undef RES_LAUNCH
   HIPCK(c, hipGetLastError());
   if (c->nprobe > 0)

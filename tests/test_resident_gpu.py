@@ -77,6 +77,61 @@ def test_resident_wide_rows(hip_lib, oracle_lib, shape, bc):
     _fields_equal(res[0].fields(), res[1].fields())
 
 
+@pytest.mark.parametrize("use_classes", [True, False])
+@pytest.mark.parametrize("shape,cells", [((56, 55, 50), 8), ((53, 47, 31), 6), ((49, 44, 30), 3), ((130, 21, 26), 5)])
+def test_resident_cpml_fields_equal_the_oracle(hip_lib, oracle_lib, shape, cells, use_classes):
+    """CPML on all six faces inside the resident kernel (psi values in registers): layers thinner than / not a multiple of the four-cell
+    groups, odd plane counts, class and raw operator; port series and NF2FF spectra as well."""
+    capi = pkg("_capi")
+    res = []
+    for lib, flags in ((hip_lib, capi.FLAG_KERNEL_RESIDENT), (oracle_lib, 0)):
+        s = patch_sim(*shape, boundary="CPML", cpml_cells=cells, nr_ts=300, use_classes=use_classes)
+        e = s.build(lib, flags=flags)
+        seeded_fields(e, 13)
+        e.run(300)
+        res.append((s, e))
+    (sh, eh), (so, eo) = res
+    assert eh.schedule_info()["resident"]
+    _fields_equal(eh.fields(), eo.fields())
+    (uh, ih), (uo, io) = sh.port_series()[0], so.port_series()[0]
+    assert rel_l2(uh, uo) < 1e-12 and rel_l2(ih, io) < 1e-12
+    for a, b in zip(sh.nf2ff_boxes(), so.nf2ff_boxes()):
+        assert rel_l2(a, b) < 1e-12
+
+
+def test_resident_mixed_mur_cpml_pec_faces(hip_lib, oracle_lib):
+    capi = pkg("_capi")
+    bc = ["MUR", "CPML", "CPML", "MUR", "PEC", "CPML"]
+    res = []
+    for lib, flags in ((hip_lib, capi.FLAG_KERNEL_RESIDENT), (oracle_lib, 0)):
+        s = patch_sim(50, 46, 33, boundary=bc, cpml_cells=6, nr_ts=300)
+        e = s.build(lib, flags=flags)
+        seeded_fields(e, 3)
+        e.run(300)
+        res.append(e)
+    assert res[0].schedule_info()["resident"]
+    _fields_equal(res[0].fields(), res[1].fields())
+
+
+def test_resident_cpml_in_chunks_equals_two_launches(hip_lib):
+    """psi, fields, probes and the NF2FF record over several resident launches (calls of 150 + 1 + 149 timesteps) ≡ 300 timesteps under two
+    launches per timestep: identical bits."""
+    capi = pkg("_capi")
+    s1 = patch_sim(56, 55, 50, boundary="CPML", cpml_cells=8, nr_ts=300, nf2ff_mode="record")
+    e1 = s1.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT)
+    e1.run(300)
+    s3 = patch_sim(56, 55, 50, boundary="CPML", cpml_cells=8, nr_ts=300, nf2ff_mode="record")
+    e3 = s3.build(hip_lib, flags=capi.FLAG_KERNEL_RESIDENT)
+    for n in (150, 1, 149):
+        e3.run(n)
+    assert e3.schedule_info()["resident"] and not e1.schedule_info()["resident"]
+    assert np.array_equal(e1.fields(), e3.fields())
+    for (u1, i1), (u3, i3) in zip(s1.port_series(), s3.port_series()):
+        assert np.array_equal(u1, u3) and np.array_equal(i1, i3) and np.abs(u1).max() > 0
+    for a, b in zip(s1.nf2ff_boxes(), s3.nf2ff_boxes()):
+        assert np.array_equal(a, b)
+
+
 def test_resident_equals_two_launch_schedule_in_chunks(hip_lib):
     """The same run under the resident schedule in calls of 1 / 7 / 100 / 61 / 131 timesteps and under three launches per timestep in one
     call: fields, probe series and recorded NF2FF spectra identical (the resident kernel cuts its launches at the sampled timesteps;
@@ -102,10 +157,9 @@ def test_resident_equals_two_launch_schedule_in_chunks(hip_lib):
 def test_auto_takes_the_resident_schedule_for_mur_scenes_only(hip_lib):
     capi = pkg("_capi")
     assert patch_sim(56, 55, 50, boundary="MUR", nr_ts=10, nf2ff=False).build(hip_lib).schedule_info()["resident"]
-    assert not patch_sim(56, 55, 50, boundary="CPML", nr_ts=10, nf2ff=False).build(hip_lib).schedule_info()["resident"]
     assert not patch_sim(56, 55, 50, boundary="MUR", nr_ts=10, nf2ff=False).build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT).schedule_info()["resident"]
     # asked for by name where it cannot run: an error code, not a fallback
-    e = patch_sim(56, 55, 50, boundary="CPML", nr_ts=10, nf2ff=False).build(hip_lib, flags=capi.FLAG_KERNEL_RESIDENT)
+    e = patch_sim(300, 300, 60, boundary="MUR", nr_ts=10, nf2ff=False).build(hip_lib, flags=capi.FLAG_KERNEL_RESIDENT)
     with pytest.raises(capi.FdtdError, match="resident schedule"):
         e.run(2)
     # too many tiles for the chip: AUTO falls back to three launches per timestep
