@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run_both(sim_factory, hip_lib, oracle_lib, steps, seed=None, flags=0):
+    import os
     out = []
     for lib in (hip_lib, oracle_lib):
         s = sim_factory()
@@ -28,6 +29,21 @@ def _run_both(sim_factory, hip_lib, oracle_lib, steps, seed=None, flags=0):
             seeded_fields(e, seed)
         e.run(steps)
         out.append((s, e))
+    # Round 4: AUTO steps small grids resident in registers (csrc/resident.hip).  The schedules AUTO took before — several timesteps per launch
+    # behind flags, two / three launches — still serve every grid that does not fit the chip: the same case once more with the resident
+    # schedule switched off, against the same oracle run.
+    if flags == 0 and out[0][1].schedule_info()["resident"]:
+        os.environ["FDTD_RESIDENT"] = "0"
+        try:
+            s = sim_factory()
+            e = s.build(hip_lib)
+        finally:
+            del os.environ["FDTD_RESIDENT"]
+        if seed is not None:
+            seeded_fields(e, seed)
+        e.run(steps)
+        assert not e.schedule_info()["resident"]
+        assert np.array_equal(e.fields(), out[1][1].fields()), "flag-coupled / multi-launch schedule != oracle"
     return out
 
 
@@ -770,20 +786,25 @@ def test_wavefront_schedule_odd_tilings_equal_two_launches(hip_lib, shape, tys, 
     assert rel_l2(s2.port_series()[0][0], s1.port_series()[0][0]) < 1e-12
 
 
-def test_kernel_schedule_selection(hip_lib):
-    """AUTO: one launch per timestep on single slabs (fdtd_profile.fused) — with all E blocks first on cache-resident grids,
-    with H a few planes behind E beyond the Infinity Cache — except small grids without CPML; small Mur scenes run resident in
-    registers (round 4); DIRECT never, WAVEFRONT always (and refused with Mur faces)."""
+def test_kernel_schedule_selection(hip_lib, monkeypatch):
+    """AUTO: small grids (at most two tiles per CU) resident in registers (round 4: fdtd_profile.fused, one launch holds many timesteps);
+    beyond that one launch per timestep on single slabs — all E blocks first on cache-resident grids, H a few planes behind E beyond the
+    Infinity Cache — except grids without CPML below 3000 blocks per sweep (two launches) and Mur scenes (three); DIRECT never,
+    WAVEFRONT always (and refused with Mur faces)."""
     capi = pkg("_capi")
     small = patch_sim(64, 60, 36, nr_ts=40, nf2ff=False)
-    assert small.build(hip_lib).run_profiled(4).fused == 1
+    assert small.build(hip_lib).schedule_info()["resident"] and small.build(hip_lib).run_profiled(4).fused == 1
     assert small.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT).run_profiled(4).fused == 0
+    mur = patch_sim(64, 60, 36, boundary="MUR", nr_ts=40, nf2ff=False)
+    assert mur.build(hip_lib).schedule_info()["resident"]
+    assert mur.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT).run_profiled(4).fused == 0
+    monkeypatch.setenv("FDTD_RESIDENT", "0")          # what AUTO takes where the resident schedule does not fit
+    assert not small.build(hip_lib).schedule_info()["resident"] and small.build(hip_lib).run_profiled(4).fused == 1
     small_pec = patch_sim(64, 60, 36, boundary="PEC", nr_ts=40, nf2ff=False)
     assert small_pec.build(hip_lib).run_profiled(4).fused == 0
     assert small_pec.build(hip_lib, flags=capi.FLAG_KERNEL_WAVEFRONT).run_profiled(4).fused == 1
-    mur = patch_sim(64, 60, 36, boundary="MUR", nr_ts=40, nf2ff=False)
-    assert mur.build(hip_lib).run_profiled(4).fused == 1          # small Mur scenes: the resident schedule (one launch holds many timesteps)
-    assert mur.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT).run_profiled(4).fused == 0
+    assert mur.build(hip_lib).run_profiled(4).fused == 0
+    monkeypatch.delenv("FDTD_RESIDENT")
     big = patch_sim(400, 400, 82, nr_ts=40, nf2ff=False)          # 6 x 84 planes x 640 KB = 323 MB
-    assert big.build(hip_lib).run_profiled(4).fused == 1
+    assert big.build(hip_lib).run_profiled(4).fused == 1 and not big.build(hip_lib).schedule_info()["resident"]
     assert big.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT).run_profiled(4).fused == 0
