@@ -500,6 +500,10 @@ __device__ __forceinline__ void cpml_x4(const DevParams& p, int eh, int i0, int 
 // ox / oz: element offsets into the psi arrays, -1 when the group is outside that layer.
 __device__ __forceinline__ int psi_off_x(const DevParams& p, const int k, const int j, const int i0) {   // -1: outside the x layers
   if (!(i0 < p.pml_lo[0] || i0 >= p.pml_hi[0])) return -1;   // both bounds are multiples of 4: all four cells or none
+#ifdef FDTD_XPSI_EMULATE_2D   // TIMING EXPERIMENT ONLY (wrong fields): the x-psi work in 2 of every 7 waves, wave-uniformly — what a 2-D wave footprint
+  // (16 groups x 4 rows) would leave of it on 400 x 400 x 80, without changing the memory access pattern: an upper bound of that idea's gain
+  if (((blockIdx.x * (FDTD_BLOCK / 64) + (threadIdx.x >> 6)) % 7u) >= 2u) return -1;
+#endif
   // product and sum kept apart (the empty asm): fused, hipcc emits v_mad_u64_u32 with an UNDEFINED high half of the 64-bit
   // addend, picks a register a field load is still in flight to for it, and guards that false dependency with
   // s_waitcnt vmcnt(0) — in front of the staged psi loads, i.e. every wave with an x-layer lane (all of them) waited for its
