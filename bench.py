@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--raw-operator", action="store_true", help="stream 12 coefficient arrays instead of class bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the C3 (HBM-resident) roofline block")
+    ap.add_argument("--no-small-grid-point", action="store_true", help="skip the reference's default GUI scene (resident schedule)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle timesteps for the cpu_baseline leg (0 = auto)")
     args = ap.parse_args()
 
@@ -229,6 +230,9 @@ def main():
         del eng
         sim.engine = None                     # frees the NS context before the C3 one is built
         hbm_point = hbm_resident_point(capi, wl, sc, simm, hip, args)
+    small_point = None
+    if rank == 0 and world == 1 and not args.no_small_grid_point:
+        small_point = small_grid_point(capi, simm, hip)
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -247,6 +251,8 @@ def main():
         }
         if hbm_point is not None:
             out["roofline_hbm_resident"] = hbm_point
+        if small_point is not None:
+            out["small_grid_point"] = small_point
         if coupling is not None:
             out["multi_gpu"] = coupling
         if cpu is not None:
@@ -332,6 +338,36 @@ def hbm_resident_point(capi, wl, sc, simm, hip, args, name="C3", steps=300):
     blk["workload"] = f"{name}: {w.grid.shape[0]}x{w.grid.shape[1]}x{w.grid.shape[2]} fixed scene, CPML-{args.cpml_cells}, {steps} timesteps"
     blk["value_mcells_s"] = round(w.grid.ncells * steps / dt / 1e6, 1)
     return blk
+
+
+def small_grid_point(capi, simm, hip):
+    """The grid the reference's GUI runs by default — prepare_*_patch_fixed: 56x55x50 graded mesh, MUR on all faces, to -40 dB
+    (solver_fdtd_openems_fixed.py:113-342) — through the plugin path, time stepping only: the resident schedule (csrc/resident.hip).  Not the
+    headline metric (latency-bound: 11 MB of algorithmic bytes per timestep); reported because it is what a user of the reference runs first."""
+    import tempfile
+    sol = importlib.import_module(PKG + ".solver_fdtd_hip")
+    par = importlib.import_module(PKG + ".params")
+    p = par.PatchAntennaParams.from_user_units(frequency_ghz=2.45, er=4.3, h_mm=1.6, loss_tangent=0.02)
+    best = None
+    with tempfile.TemporaryDirectory() as td:
+        for rep in range(2):           # (the first call pays the table set-up of a new context shape)
+            prep = sol.prepare_hip_patch_fixed(p, work_dir=os.path.join(td, f"w{rep}"))
+            if not prep.ok:
+                return {"error": prep.message}
+            res = sol.run_prepared_hip(prep, frequency_hz=p.frequency_hz, verbose=0)
+            if not res.ok:
+                return {"error": res.message}
+            st = res.stats
+            sched = prep.FDTD.sim.engine.schedule_info()
+            rec = {"workload": f"reference default scene (fixed): {st['grid'][0]}x{st['grid'][1]}x{st['grid'][2]} graded mesh, MUR, to -40 dB",
+                   "timesteps": st["steps"], "seconds_stepping": round(st["seconds"], 4), "value_mcells_s": round(st["mcells_per_s"], 1),
+                   "us_per_timestep": round(st["seconds"] / max(st["steps"], 1) * 1e6, 3), "energy_db": round(st["energy_db"], 2),
+                   "schedule": "resident in registers" if sched["resident"] else f"{sched['launches_per_timestep']} launch(es) per timestep",
+                   "workgroups": sched["blocks_per_sweep"], "algorithmic_bytes_per_timestep": 72 * st["cells"],
+                   "bound": "latency (two device-scope tile-halo hops per timestep)", "Dmax_dBi": round(float(10 * np.log10(res.Dmax)), 3)}
+            if best is None or rec["value_mcells_s"] > best["value_mcells_s"]:
+                best = rec
+    return best
 
 
 def pmc_traffic(workload, kernel, world):

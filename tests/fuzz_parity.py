@@ -3,7 +3,7 @@
 
 Every case draws a grid shape (odd sizes, rows of 2 ... 65 four-cell groups, 12 ... 48 planes), a boundary per face (PEC / MUR / CPML, or
 CPML on all six), a layer thickness, the operator form (class bytes / raw arrays), the kernel schedule (AUTO, two launches per timestep,
-one launch per timestep forced), the tiling ($FDTD_TYS), the timesteps per launch ($FDTD_WF_MULTI), whether the XCD shares are measured
+one launch per timestep forced, resident in registers forced), the tiling ($FDTD_TYS), the timesteps per launch ($FDTD_WF_MULTI), whether the XCD shares are measured
 ($FDTD_XCD_ADAPT), NF2FF faces as running sums / recorded samples / none, random initial fields, and a list of run() calls of random
 length (the launches of several timesteps are cut at calls and at NF2FF sample steps).  The same list goes to both engines through the
 same C ABI; compared: all six field components as IEEE values (bit for bit wherever the oracle's value is non-zero), the port series and
@@ -29,7 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = "fdtd-solver-antennas_amd"
-ENV_KNOBS = ("FDTD_TYS", "FDTD_WF_MULTI", "FDTD_XCD_ADAPT", "FDTD_WF_LAG")
+ENV_KNOBS = ("FDTD_TYS", "FDTD_WF_MULTI", "FDTD_XCD_ADAPT", "FDTD_WF_LAG", "FDTD_RESIDENT", "FDTD_RES_CHUNK")
 
 
 def _mod(name):
@@ -53,8 +53,14 @@ def draw_case(rng):
     cells_max = max(2, min(12, (min(nx, ny, nz) - 8) // 2))
     cells = int(rng.integers(2, cells_max + 1))
     has_mur = "MUR" in kinds
-    sched = str(rng.choice(["auto", "direct"] if has_mur else ["auto", "direct", "wavefront", "wavefront"]))
+    sched = str(rng.choice(["auto", "direct", "resident"] if has_mur else ["auto", "direct", "wavefront", "wavefront", "resident"]))
     env = {}
+    # round 4: AUTO steps small grids resident in registers; half of the AUTO cases keep the schedules AUTO took before (they still serve
+    # every grid that does not fit the chip), and the resident launches are cut short now and then
+    if sched == "auto" and rng.random() < 0.5:
+        env["FDTD_RESIDENT"] = "0"
+    if rng.random() < 0.3:
+        env["FDTD_RES_CHUNK"] = str(int(rng.choice([1, 2, 7, 33])))
     if rng.random() < 0.4:
         env["FDTD_TYS"] = str(int(rng.choice([1, 2, 3, 4, 5, 7, 9, 16, 40])))
     if rng.random() < 0.5:
@@ -75,7 +81,7 @@ def run_case(case, hip, oracle):
     nx, ny, nz = case["shape"]
     w = wl.patch_workload("fuzz", nx=nx, ny=ny, nz=nz)
     vox = sc.voxelize(w.scene, w.grid)
-    flags = {"auto": 0, "direct": capi.FLAG_KERNEL_DIRECT, "wavefront": capi.FLAG_KERNEL_WAVEFRONT}[case["sched"]]
+    flags = {"auto": 0, "direct": capi.FLAG_KERNEL_DIRECT, "wavefront": capi.FLAG_KERNEL_WAVEFRONT, "resident": capi.FLAG_KERNEL_RESIDENT}[case["sched"]]
     total = sum(case["calls"])
     saved = {k: os.environ.pop(k, None) for k in ENV_KNOBS}
     os.environ.update(case["env"])
@@ -239,6 +245,9 @@ def run_batch(ncases, seed, hip, oracle, only=None, log=print, slabs=False):
             log(f"case {n}: skipped ({exc}) {case}")
             continue
         except _mod("_capi").FdtdError as exc:      # an error from the library (a bounded wait that ran out, ...) is a failing case
+            if "(-5): resident schedule" in str(exc):    # ... or a grid the resident schedule, asked for by name, cannot hold
+                log(f"case {n}: refused ({str(exc)[:120]}) {case}")
+                continue
             if "not starvation-free" in str(exc):    # ... except a drawn decomposition the library REFUSES: slabs sharing the test GPU that could pin every workgroup slot
                 log(f"case {n}: refused ({str(exc)[:150]}...) {case}")
                 continue

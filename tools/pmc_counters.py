@@ -14,7 +14,7 @@ for gi, grp in enumerate(groups):
     subprocess.run(["rm", "-rf", d])
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *grp.split(","), "--output-format", "csv", "-d", d, "-o", "pmc", "--",
            "python3", os.path.join(root, "bench.py"), "--workload", wl, "--steps", "2", "--warmup", "1", "--ts-per-step", "10",
-           "--no-cpu-baseline", "--no-hbm-point"]
+           "--no-cpu-baseline", "--no-hbm-point", "--no-small-grid-point"]
     r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-3000:])

@@ -18,7 +18,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     subprocess.run(["rm", "-rf", d])
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-           "python3", os.path.join(root, "bench.py"), "--workload", wl, "--steps", "2", "--warmup", "1", "--ts-per-step", "10", "--no-cpu-baseline", "--no-hbm-point", "--prefill-seconds", "0"]
+           "python3", os.path.join(root, "bench.py"), "--workload", wl, "--steps", "2", "--warmup", "1", "--ts-per-step", "10", "--no-cpu-baseline", "--no-hbm-point", "--no-small-grid-point", "--prefill-seconds", "0"]
     r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-2000:])
