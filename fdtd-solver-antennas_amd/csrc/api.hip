@@ -200,6 +200,10 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   if (const char* v = getenv("FDTD_XCD_WY")) c->xw_y = std::max(0.0, std::min(4.0, atof(v)));
   if (const char* v = getenv("FDTD_XCD_WZ")) c->xw_z = std::max(0.0, std::min(4.0, atof(v)));
   if (const char* v = getenv("FDTD_XCD_WYZ")) c->xw_yz = std::max(0.0, std::min(4.0, atof(v)));
+  // The block -> XCD mapping of the update kernels (index % 8), the cost-weighted shares and their measured correction describe the WHOLE chip:
+  // 8 XCDs of 32 CUs.  On a partitioned gfx950 (CPX / DPX logical devices: 32 / 128 CUs, 1 / 4 XCDs) results are unaffected, but eight weighted
+  // shares would split one XCD's work into padded pieces and the adaptation would fit noise: equal shares, no adaptation there.
+  if (chip_cus(d->device) != 256 && !getenv("FDTD_XCD_BALANCE")) { c->xcd_balance = false; c->xcd_adapt = false; }
   p.src_dense_ok = 1;
   p.src_rng = nullptr; p.src_ids = nullptr; p.nsrc = 0; p.src_off = nullptr; p.src_comp = nullptr; p.src_amp = nullptr; p.src_delay = nullptr;
   p.sig = c->sig; p.nsig = 0;
