@@ -34,6 +34,9 @@ namespace {
 
 constexpr int RES_MAX_SRC = 128;     // soft-source edges one tile can hold (the reference's ports have 4-16)
 constexpr int RES_MAX_PRB = 256;
+#ifndef RES_POLL_SLEEP
+#define RES_POLL_SLEEP 0      // s_sleep units (64 clocks) between two polling rounds of a halo that has not arrived
+#endif
      // probe cells one tile can hold (a lumped port: 4 + 8-16)
 
 struct ResDev {
@@ -86,6 +89,9 @@ __device__ __forceinline__ void gx_pull(const ResDev& r, const DevRsrc rs, const
     if (__ballot(pk || pj) == 0ull) break;
     // (Polling harder or softer changes nothing: pausing between rounds, or probing one 16-byte piece per pair until its tags are there,
     // left the timestep where it was — profiles/r04/resident_phase_trace.txt.  What a waiting workgroup waits for is the hop itself.)
+#if RES_POLL_SLEEP > 0
+    __builtin_amdgcn_s_sleep(RES_POLL_SLEEP);
+#endif
     if ((round & 31) != 31) continue;
     if (t0 == 0ull) t0 = wall_clock64();
     if (__hip_atomic_load(r.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;

@@ -355,15 +355,18 @@ def test_northstar_acceptance(hip_lib, oracle_lib):
     assert max(out["rel_l2"].values()) < 1e-6, out["rel_l2"]
 
 
-@pytest.mark.parametrize("overlap", ["split", "nosplit"])
-def test_rccl_self_loopback_transport(hip_lib, oracle_lib, overlap):
+@pytest.mark.parametrize("overlap", ["split", "nosplit", "inline"])
+def test_rccl_self_loopback_transport(hip_lib, oracle_lib, overlap, monkeypatch):
     """The RCCL calls themselves on one GPU: an interior slab (rank 1 of 3) whose halos go to ITSELF through
     ncclSend/ncclRecv in a communicator of one (FDTD_FLAG_LOOPBACK) — the library's own step loop, communication
     stream, events and overlap split — against the same slab stepped by half-steps with its halo planes copied back
     through the host, on the HIP library and on the oracle.  Interior planes have live coefficients on both faces, so
     a wrong plane, component, count or ordering changes the fields."""
     capi = pkg("_capi")
-    flag = capi.FLAG_LOOPBACK | (capi.FLAG_OVERLAP_ON if overlap == "split" else capi.FLAG_OVERLAP_OFF)
+    flag = capi.FLAG_LOOPBACK | (capi.FLAG_OVERLAP_OFF if overlap == "nosplit" else capi.FLAG_OVERLAP_ON)
+    # round 4: a slab this thin exchanges in stream order on the compute stream under AUTO ("inline"); the overlapped schedule (communication
+    # stream, events, split sweeps) serves the thick slabs: forced here for the first two cases
+    monkeypatch.setenv("FDTD_RCCL_INLINE", "1" if overlap == "inline" else "0")
     n = 120
 
     def slab(lib, flags):
