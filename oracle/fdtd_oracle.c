@@ -146,6 +146,21 @@ static real* take_table(int kind, const float* src, size_t n) {
   return d;
 }
 
+/* State and operator in the working precision's full width (oracle-only; the ABI's getters round to float32): what the exact discrete identities
+ * of tests/test_oracle_invariants_cpu.py are checked on. */
+int fdtd_oracle_get_field_f64(fdtd_ctx* c, int kind, int comp, double* out) {
+  if (!c || !out || comp < 0 || comp > 2 || (kind != 0 && kind != 1)) return FDTD_E_ARG;
+  const real* src = (kind == FDTD_KIND_V ? c->V : c->I)[comp];
+  for (size_t q = 0; q < c->nloc; ++q) out[q] = (double)src[q];
+  return FDTD_OK;
+}
+int fdtd_oracle_get_operator_f64(fdtd_ctx* c, double* vv, double* vi, double* ii, double* iv) {
+  if (!c || !vv || !vi || !ii || !iv) return FDTD_E_ARG;
+  if (!c->have_op) return FDTD_E_STATE;
+  for (size_t q = 0; q < 3 * c->nloc; ++q) { vv[q] = (double)c->vv[q]; vi[q] = (double)c->vi[q]; ii[q] = (double)c->ii[q]; iv[q] = (double)c->iv[q]; }
+  return FDTD_OK;
+}
+
 int fdtd_version(void) { return FDTD_ABI_VERSION; }
 int fdtd_device_count(void) { return 0; }
 const char* fdtd_backend(void) { return "oracle:cpu"; }

@@ -71,3 +71,16 @@ def test_many_source_edges_equal_the_oracle(hip_lib, oracle_lib, boundary, flag)
     assert np.abs(fo).max() > 0 and np.array_equal(fh, fo)
     (uh, ih), (uo, io) = sh.port_series()[0], so.port_series()[0]
     assert np.abs(uo).max() > 0 and np.allclose(uh, uo, rtol=1e-12, atol=0) and np.allclose(ih, io, rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize("flag", ["AUTO", "DIRECT", "WAVEFRONT"])
+def test_discrete_poynting_theorem_on_the_gpu(hip_lib, flag):
+    """The exact energy balance of the scheme (tests/test_oracle_invariants_cpu.py), stepped one timestep at a time by libfdtd_hip.so under the
+    resident, the two-launch and the flag-coupled schedule: every timestep's balance closes to float32 round-off."""
+    import test_oracle_invariants_cpu as inv
+    capi = pkg("_capi")
+    sim = inv._scene()
+    e = sim.build(hip_lib, flags={"AUTO": 0, "DIRECT": capi.FLAG_KERNEL_DIRECT, "WAVEFRONT": capi.FLAG_KERNEL_WAVEFRONT}[flag])
+    worst, q0, q_end = inv._identity(hip_lib, e, sim, 60, False)
+    assert e.schedule_info()["resident"] == (flag == "AUTO")
+    assert q_end < (1 - 5e-6) * q0 and worst < 1e-7, worst
