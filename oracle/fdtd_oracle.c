@@ -154,6 +154,12 @@ int fdtd_oracle_get_field_f64(fdtd_ctx* c, int kind, int comp, double* out) {
   for (size_t q = 0; q < c->nloc; ++q) out[q] = (double)src[q];
   return FDTD_OK;
 }
+int fdtd_oracle_set_field_f64(fdtd_ctx* c, int kind, int comp, const double* in) {
+  if (!c || !in || comp < 0 || comp > 2 || (kind != 0 && kind != 1)) return FDTD_E_ARG;
+  real* dst = (kind == FDTD_KIND_V ? c->V : c->I)[comp];
+  for (size_t q = 0; q < c->nloc; ++q) dst[q] = (real)in[q];
+  return FDTD_OK;
+}
 int fdtd_oracle_get_operator_f64(fdtd_ctx* c, double* vv, double* vi, double* ii, double* iv) {
   if (!c || !vv || !vi || !ii || !iv) return FDTD_E_ARG;
   if (!c->have_op) return FDTD_E_STATE;

@@ -101,3 +101,63 @@ def test_discrete_poynting_theorem_float32_oracle(oracle_lib):
     e = sim.build(oracle_lib)
     worst, q0, q_end = _identity(oracle_lib, e, sim, 120, False)
     assert q_end < (1 - 1e-5) * q0 and worst < 1e-7, worst
+
+
+def _cavity(n=16, delta=2.0e-3):
+    sc, simm, grid_mod = pkg("scene"), pkg("simulation"), pkg("grid")
+    lines = np.arange(n + 1) * delta
+    grid = grid_mod.RectGrid(lines, lines * 0.75, lines * 1.25)          # cells of 2.0 x 1.5 x 2.5 mm: a different spacing per axis
+    vox = sc.voxelize(sc.Scene(unit=1.0), grid)
+    return simm.Simulation(grid, vox, f0=1e9, fc=5e8, boundary="PEC", nr_ts=400, nf2ff_freqs=None), grid
+
+
+@pytest.mark.parametrize("dbl", [True, False])
+def test_numerical_dispersion_relation_is_exact(oracle_lib, dbl):
+    _dispersion(load_oracle_f64() if dbl else oracle_lib, dbl)
+
+
+def _dispersion(lib, dbl, flags=0):
+    """"numerical dispersion vs analytic".  In a PEC box on a uniform grid E_y = sin(k_x x_i) sin(k_z z_k) is an EXACT eigenvector
+    of the discrete curl-curl operator, so every edge voltage obeys V(n+1) + V(n-1) = 2 cos(w dt) V(n) with the Yee dispersion relation
+    sin^2(w dt / 2) = (c dt)^2 [sin^2(k_x dx / 2) / dx^2 + sin^2(k_z dz / 2) / dz^2] — which sees what the energy identity cannot: the constants
+    (eps0, mu0, dt) and the metric in the coefficients.  Mode (3, 0, 2) on 16 cells per side (5 - 8 cells per half wavelength): the discrete
+    frequency lies 1-2 % below the continuum's, and the engine follows the DISCRETE one to round-off."""
+    consts = pkg("constants")
+    sim, grid = _cavity()
+    e = build_f64(sim, lib, double_tables=True) if dbl else sim.build(lib, flags=flags)
+    nx, ny, nz = grid.shape
+    m, p = 3, 2
+    dx, dz = grid.x[1] - grid.x[0], grid.z[1] - grid.z[0]
+    kx, kz = m * np.pi / (grid.x[-1] - grid.x[0]), p * np.pi / (grid.z[-1] - grid.z[0])
+    shape = np.sin(kx * (grid.x - grid.x[0]))[None, None, :] * np.sin(kz * (grid.z - grid.z[0]))[:, None, None] * np.ones((1, ny, 1))
+    shape[:, -1, :] = 0.0                                   # (the y edge from the last node does not exist)
+    if dbl:      # (the ABI's setter rounds to float32: the mode would carry 6e-8 of every other mode)
+        lib.fdtd_oracle_set_field_f64.restype = ctypes.c_int
+        sh64 = np.ascontiguousarray(shape, np.float64)
+        assert lib.fdtd_oracle_set_field_f64(e._ctx, 0, 1, sh64.ctypes.data_as(ctypes.c_void_p)) == 0
+    else:
+        e.set_field(0, 1, shape.astype(np.float32))
+    s2 = (consts.C0 * sim.dt) ** 2 * (np.sin(kx * dx / 2) ** 2 / dx ** 2 + np.sin(kz * dz / 2) ** 2 / dz ** 2)
+    w_num = 2.0 * np.arcsin(np.sqrt(s2)) / sim.dt
+    w_cont = consts.C0 * np.hypot(kx, kz)
+    assert 0.005 < 1.0 - w_num / w_cont < 0.03               # a coarse mode: the grid's own frequency, visibly below the continuum's
+
+    def vy():
+        if dbl:
+            out = np.empty(nx * ny * nz)
+            lib.fdtd_oracle_get_field_f64.restype = ctypes.c_int
+            assert lib.fdtd_oracle_get_field_f64(e._ctx, 0, 1, out.ctypes.data_as(ctypes.c_void_p)) == 0
+            return out.reshape(nz, ny, nx)
+        return np.asarray(e.get_field(0, 1), np.float64)
+    hist = [vy()]
+    for _ in range(200):
+        e.run(1)
+        hist.append(vy())
+    a = np.abs(hist[0]).max()
+    resid = max(np.abs(hist[n + 1] + hist[n - 1] - 2.0 * np.cos(w_num * sim.dt) * hist[n]).max() for n in range(1, 200)) / a
+    assert resid < (1e-13 if dbl else 2e-6), resid
+    # the other components stay zero: the mode is an eigenvector, nothing leaks
+    assert max(np.abs(np.asarray(e.get_field(0, c))).max() for c in (0, 2)) <= (1e-12 if dbl else 1e-5) * a
+    # and with the CONTINUUM frequency the same recurrence is off by the dispersion error, orders of magnitude above round-off
+    off = max(np.abs(hist[n + 1] + hist[n - 1] - 2.0 * np.cos(w_cont * sim.dt) * hist[n]).max() for n in range(1, 200)) / a
+    assert off > 1e-3

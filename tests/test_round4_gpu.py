@@ -84,3 +84,12 @@ def test_discrete_poynting_theorem_on_the_gpu(hip_lib, flag):
     worst, q0, q_end = inv._identity(hip_lib, e, sim, 60, False)
     assert e.schedule_info()["resident"] == (flag == "AUTO")
     assert q_end < (1 - 5e-6) * q0 and worst < 1e-7, worst
+
+
+@pytest.mark.parametrize("flag", ["AUTO", "DIRECT"])
+def test_numerical_dispersion_relation_on_the_gpu(hip_lib, flag):
+    """A cavity eigenmode stepped by libfdtd_hip.so follows the Yee dispersion relation of the GRID (1-2 % below the continuum's frequency for this
+    mode) to float32 round-off: tests/test_oracle_invariants_cpu.py::_dispersion."""
+    import test_oracle_invariants_cpu as inv
+    capi = pkg("_capi")
+    inv._dispersion(hip_lib, False, flags={"AUTO": 0, "DIRECT": capi.FLAG_KERNEL_DIRECT}[flag])
