@@ -462,7 +462,7 @@ def prepare_hip_microstrip_multi_3d(patches: Sequence, *, dll_dir: Optional[str]
             start = [float(c_w[0] - half), float(c_w[1] - half), float(c_w[2] - half)]
             stop = [float(c_w[0] + half), float(c_w[1] + half), float(c_w[2] + half)]
             start[axis], stop[axis] = s0, s1
-            for a in [axis] + [b for b in ((0, 1, 2) if axis == 2 else (0, 1, 2)) if b != axis]:
+            for a in [axis] + [b for b in (0, 1, 2) if b != axis]:
                 mesh.AddLine("xyz"[a], [start[a], float(c_w[a]), stop[a]])
             if verbose:
                 say(f"Patch {idx}: center(mm)={np.round(T, 3).tolist()} rot={rot} port axis={axis} "
