@@ -1,12 +1,12 @@
 // resident.hip — small grids: the whole grid RESIDENT IN REGISTERS for the length of a launch (k_resident).
 //
-// Why.  The reference GUI's default scenes (prepare_*_patch_fixed and its siblings: 56x55x50 ... 86x71x52 nodes, MUR faces,
-// solver_fdtd_openems_fixed.py:173, solver_fdtd_openems_microstrip.py:134-145) are 0.15-0.3 Mcells: 4-7 MB of fields on a
-// chip with 128 MB of vector registers.  Stepped as sweeps over arrays, each timestep is three dependent launches (E + Mur
+// Why.  The reference GUI's default scenes (prepare_*_patch_fixed and its siblings: 56x55x50 ... 86x71x52 nodes, MUR or PML_8 faces,
+// solver_fdtd_openems_fixed.py:173, solver_fdtd_openems_microstrip.py:134-145, gui_app.py:190) are 0.15-0.3 Mcells: 4-7 MB of fields on a
+// chip with 128 MB of vector registers.  Stepped as sweeps over arrays, a Mur timestep is three dependent launches (E + Mur
 // post, Mur apply, H + Mur pre) of 4-7 us each — every one at its launch / memory-latency floor, 14-16 us per timestep for 11 MB
-// of algorithmic bytes (profiles/r04/before/mur_scene_kernel_gaps.txt: the device is busy with those kernels, not idle between
-// them), and several timesteps per launch behind per-block flags (k_step<.., MULTI>) cannot get below a block's life time per
-// half-step either (load round trip + store drain + flag hop: ~6 us).
+// of algorithmic bytes (profiles/r04/mur_scene/before_three_launches_kernel_gaps.txt: the device is busy with those kernels, not idle
+// between them), and several timesteps per launch behind per-block flags (k_step<.., MULTI>: the CPML twins) cannot get below a block's
+// life time per half-step either (load round trip + store drain + flag hop: ~6 us; 12-20 us per timestep on these grids).
 //
 // Here a workgroup OWNS a tile of the grid — ZT planes x R rows x all of x, one thread = 4 x-cells of one row of one plane — and
 // keeps its six field vectors AND its update coefficients in registers from the first timestep of a launch to the last.  Per
@@ -14,11 +14,13 @@
 //   * inside the tile: through LDS (every thread leaves its new vectors there; one barrier per half-step);
 //   * across tiles: as data-tagged GRANULES {value, tag} through a device-scope exchange buffer (the mailbox protocol of the
 //     multi-GPU halo transport, kernel_common.hpp, between workgroups of one launch): the producer stores its boundary rows /
-//     planes write-through once and goes on, the consumer loads them and looks at the tags — ONE hop of ~1 us per half-step
-//     (MI355X_MICROARCH.md, handoff-1to1) instead of a kernel boundary + a cold memory round trip.  No flags, no atomics.
+//     planes write-through once and goes on, the consumer loads them and looks at the tags — ONE hop per half-step (measured 1.7 us between
+//     loaded CUs, profiles/r04/resident_phase_trace.txt; MI355X_MICROARCH.md, handoff-1to1: 0.8-2.9 us) instead of a kernel boundary + a
+//     cold memory round trip.  No flags, no atomics.
 // Tiles pair the planes {0, 1} and {nk-2, nk-1} (and whole rows), so every first-order Mur update — boundary point and its inner
 // neighbour — is inside ONE tile: candidates from LDS snapshots of the old and the freshly updated voltages, later face wins on
-// shared edges, exactly k_mur's pre / post / apply.  Sources are applied by the threads that own their edges; probe cells are
+// shared edges, exactly k_mur's pre / post / apply.  CPML: the psi values of a thread's layer cells live in registers as well (res_cpml).
+// Sources are applied by the threads that own their edges; the NF2FF faces are recorded by the threads that own their cells; probe cells are
 // staged per timestep and reduced after the launch by probe_block's tree (identical sums).  All workgroups must be resident at
 // once (they wait for each other): the launcher checks the grid against the occupancy query, every wait is bounded
 // (error word -> FDTD_E_DEVICE, simulation.Simulation.run repeats the run under the two-launch schedule).
@@ -32,12 +34,11 @@
 
 namespace {
 
-constexpr int RES_MAX_SRC = 128;     // soft-source edges one tile can hold (the reference's ports have 4-16)
-constexpr int RES_MAX_PRB = 256;
+constexpr int RES_MAX_SRC = 128;     // soft-source edges one tile can hold (the reference's single-patch ports have 4-16)
+constexpr int RES_MAX_PRB = 256;     // probe cells one tile can hold (a lumped port: 4 + 8-16)
 #ifndef RES_POLL_SLEEP
-#define RES_POLL_SLEEP 0      // s_sleep units (64 clocks) between two polling rounds of a halo that has not arrived
+#define RES_POLL_SLEEP 0      // s_sleep units (64 clocks) between two polling rounds of a halo that has not arrived (0 / 2 / 8 measured alike)
 #endif
-     // probe cells one tile can hold (a lumped port: 4 + 8-16)
 
 struct ResDev {
   int nzt, nstrips;          // z tiles, strips (a workgroup = one z tile x one strip, all of x)
