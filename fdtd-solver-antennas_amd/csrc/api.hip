@@ -228,6 +228,7 @@ void fdtd_destroy(fdtd_ctx* c) {
   for (int n = 0; n < 12; ++n) hipFree(c->psi[n]);
   for (int f = 0; f < 6; ++f) { hipFree(c->mur[f].st[0]); hipFree(c->mur[f].st[1]); }
   hipFree(c->d_mur);
+  hipFree(c->rt_tw[0]); hipFree(c->rt_tw[1]); hipFree(c->rt_out);
   hipFree(c->sig); hipFree(c->src_off); hipFree(c->src_comp); hipFree(c->src_amp); hipFree(c->src_delay);
   for (int q = 0; q < c->nprobe; ++q) {
     hipFree((void*)c->probe[q].off); hipFree((void*)c->probe[q].comp); hipFree((void*)c->probe[q].w); hipFree(c->probe[q].series);
@@ -633,17 +634,33 @@ int fdtd_rec_transform(fdtd_ctx* c, int id, int nfreq, const double* tw, double*
   HIPCK(c, hipSetDevice(c->d.device));
   // samples taken so far: steps 0, every, 2*every, ... of the half-steps already done
   const int ns = (int)std::min<int64_t>((c->step + c->every - 1) / c->every, c->nsamples);
-  double *d_tw = nullptr, *d_out = nullptr;
-  const size_t tw_bytes = (size_t)std::max(ns, 1) * nfreq * 2 * sizeof(double), out_bytes = (size_t)bx.npts * nfreq * 2 * sizeof(double);
-  hipError_t e = hipMalloc(&d_tw, tw_bytes);
-  if (e == hipSuccess) e = hipMalloc(&d_out, out_bytes);
-  if (e == hipSuccess && ns > 0) e = hipMemcpyAsync(d_tw, tw, (size_t)ns * nfreq * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  // Device scratch kept in the context (CalcNF2FF transforms 24 boxes with two twiddle tables — E-located and H-located sample times —, one call
+  // each: allocating, uploading and freeing per call was most of the 6 ms the transform took on the reference's default scene): two twiddle slots
+  // recognised by content, one output buffer grown on demand.
+  const size_t tw_n = (size_t)std::max(ns, 0) * nfreq * 2, out_bytes = (size_t)bx.npts * nfreq * 2 * sizeof(double);
+  int slot = -1;
+  for (int q = 0; q < 2; ++q)
+    if (c->rt_tw[q] && c->rt_tw_host[q].size() == tw_n && (tw_n == 0 || memcmp(c->rt_tw_host[q].data(), tw, tw_n * sizeof(double)) == 0)) slot = q;
+  hipError_t e = hipSuccess;
+  if (slot < 0) {
+    slot = c->rt_next; c->rt_next ^= 1;
+    hipFree(c->rt_tw[slot]); c->rt_tw[slot] = nullptr; c->rt_tw_host[slot].clear();
+    e = hipMalloc(&c->rt_tw[slot], std::max<size_t>(tw_n, 1) * sizeof(double));
+    if (e == hipSuccess && tw_n) e = hipMemcpyAsync(c->rt_tw[slot], tw, tw_n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);     // (the caller's table may go away after this call)
+    if (e == hipSuccess) c->rt_tw_host[slot].assign(tw, tw + tw_n);
+    else { hipFree(c->rt_tw[slot]); c->rt_tw[slot] = nullptr; }
+  }
+  if (e == hipSuccess && c->rt_out_bytes < out_bytes) {
+    hipFree(c->rt_out); c->rt_out = nullptr; c->rt_out_bytes = 0;
+    e = hipMalloc(&c->rt_out, out_bytes);
+    if (e == hipSuccess) c->rt_out_bytes = out_bytes;
+  }
   if (e == hipSuccess) {
-    launch_rec_dft(bx.rec, bx.npts, ns, nfreq, d_tw, d_out, c->stream);
-    e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+    launch_rec_dft(bx.rec, bx.npts, ns, nfreq, c->rt_tw[slot], c->rt_out, c->stream);
+    e = hipMemcpyAsync(out, c->rt_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(d_tw); hipFree(d_out);
   HIPCK(c, e);
   return FDTD_OK;
 }

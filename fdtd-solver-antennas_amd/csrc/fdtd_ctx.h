@@ -224,6 +224,9 @@ struct fdtd_ctx {
   int nbox = 0; DevBox box[FDTD_MAX_BOXES] = {}; DevBox* d_box = nullptr;
   int32_t box_lo[FDTD_MAX_BOXES][3] = {}, box_hi[FDTD_MAX_BOXES][3] = {};
   long box_maxpts[2] = {0, 0};
+  // fdtd_rec_transform: device scratch kept between calls (two twiddle tables recognised by content, one output buffer)
+  double* rt_tw[2] = {nullptr, nullptr}; std::vector<double> rt_tw_host[2]; int rt_next = 0;
+  double* rt_out = nullptr; size_t rt_out_bytes = 0;
   // stepping
   int64_t step = 0;
   double* d_energy = nullptr;
