@@ -155,9 +155,12 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   CK(hipEventCreateWithFlags(&c->ev_haloE, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_haloH, hipEventDisableTiming));
   const size_t fbytes = (size_t)plane * (d->nk + 2) * sizeof(float);
+  // behind every voltage array: room for the Mur candidates of its component (four faces: kernels.hip build_mur_table, mur_load_V)
+  c->mur_tail = 4 * ((size_t)d->ny * P + (size_t)d->nk * P + (size_t)d->nk * d->ny) + 64 + P;   // (cd and st)
   for (int n = 0; n < 6; ++n) {
-    CK(hipMalloc(&c->fieldbase[n], fbytes));
-    CK(hipMemset(c->fieldbase[n], 0, fbytes));
+    const size_t bytes = fbytes + (n < 3 ? c->mur_tail * sizeof(float) : 0);
+    CK(hipMalloc(&c->fieldbase[n], bytes));
+    CK(hipMemset(c->fieldbase[n], 0, bytes));
   }
   CK(hipMalloc(&c->d_energy, (2 + 2 * ENERGY_BLOCKS + 1) * sizeof(double)));
   CK(hipMemset(c->d_energy, 0, (2 + 2 * ENERGY_BLOCKS + 1) * sizeof(double)));
@@ -185,6 +188,7 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   if (const char* v = getenv("FDTD_OCC_E")) c->occ_e = std::max(0, std::min(16, atoi(v)));
   if (const char* v = getenv("FDTD_NT")) p.nt = atoi(v) ? 1 : 0;                       // experiments
   if (const char* v = getenv("FDTD_OCC_WF")) c->occ_wf = std::max(0, std::min(16, atoi(v)));
+  if (const char* e = getenv("FDTD_MUR_APPLY_PASS")) c->mur_no_apply = atoi(e) == 0;   // =1: keep the apply pass as a launch of its own (A/B, tests)
   if (getenv("FDTD_MUR_UNFUSED")) c->mur_fuse_post = false;   // experiments: the Mur post pass as a launch of its own
   if (const char* v = getenv("FDTD_WAVEFRONT")) c->wf_mode = atoi(v) ? 1 : 0;
   if (const char* v = getenv("FDTD_WF_LAG")) c->wf_lag = std::max(0, std::min(4096, atoi(v)));
@@ -226,7 +230,6 @@ void fdtd_destroy(fdtd_ctx* c) {
   hipFree(c->wf_flags); hipFree(c->wf_err); hipFree(c->wf_flagsH); hipFree(c->wf_prb_sp); hipFree(c->wf_prb_blk); hipFree(c->wf_prb_rng);
   hipFree(c->wf_prbV_sp); hipFree(c->wf_prb_done);
   for (int n = 0; n < 12; ++n) hipFree(c->psi[n]);
-  for (int f = 0; f < 6; ++f) { hipFree(c->mur[f].st[0]); hipFree(c->mur[f].st[1]); }
   hipFree(c->d_mur);
   hipFree(c->rt_tw[0]); hipFree(c->rt_tw[1]); hipFree(c->rt_out);
   hipFree(c->sig); hipFree(c->src_off); hipFree(c->src_comp); hipFree(c->src_amp); hipFree(c->src_delay);
@@ -441,16 +444,11 @@ int fdtd_set_mur(fdtd_ctx* c, const int32_t enable[6], const float coeff[6]) {
       else if (on && c->d.nk < 2) return fdtd_fail(c, FDTD_E_UNSUPPORTED, "Mur z face needs nk >= 2");
     }
     const size_t n = a == 0 ? (size_t)c->d.nk * c->d.ny : a == 1 ? (size_t)c->d.nk * c->d.nx : (size_t)c->d.ny * c->d.nx;
-    for (int t = 0; t < 2; ++t) {
-      hipFree(c->mur[f].st[t]); c->mur[f].st[t] = nullptr;
-      if (on) {
-        HIPCK(c, hipMalloc(&c->mur[f].st[t], n * sizeof(float)));
-        HIPCK(c, hipMemset(c->mur[f].st[t], 0, n * sizeof(float)));
-      }
-    }
     c->mur[f].on = on; c->mur[f].coeff = coeff[f]; c->mur[f].n = (int)n;
     c->any_mur |= on != 0;
   }
+  for (int n = 0; n < 3; ++n)   // the candidates behind the voltage arrays: a new set of faces starts from zeros
+    HIPCK(c, hipMemset(c->fieldbase[n] + (size_t)c->plane * (c->d.nk + 2), 0, c->mur_tail * sizeof(float)));
   return build_mur_table(c);
 }
 
@@ -778,6 +776,40 @@ static bool sources_fusable(const fdtd_ctx* c) {
   return true;
 }
 
+// Mur faces without an apply pass (two launches per timestep instead of three).  Between update_E and update_H the boundary
+// voltages in memory are then the E update's own, and inside update_H they are being overwritten: whoever reads V there —
+// V-probes (sampled by update_H's extra block), NF2FF / DFT boxes (sampled between the two launches) — must not hold a
+// node of a Mur face.  (The reference's probes and boxes sit inside the grid.)  Same conditions as the post pass inside
+// update_E otherwise (phase_E).
+static bool mur_direct_possible(const fdtd_ctx* c, bool multi, bool fused) {
+  if (!c->mur_no_apply || !c->any_mur || multi || !fused || !c->d_mur || !c->mur_fuse_post) return false;
+  if (c->d.nx < 6 || c->d.ny < 5 || c->d.nz < 5) return false;
+  const int dim[3] = {c->d.nx, c->d.ny, c->d.nk};
+  auto on_face = [&](const int lo[3], const int hi[3]) {
+    for (int f = 0; f < 6; ++f) {
+      if (!c->mur[f].on) continue;
+      const int a = f / 2, b = (f & 1) ? dim[a] - 1 : 0;
+      if (lo[a] <= b && b <= hi[a]) return true;
+    }
+    return false;
+  };
+  for (int q = 0; q < c->nprobe; ++q) {
+    if (c->probe[q].kind != FDTD_KIND_V) continue;
+    for (int off : c->h_prb_off[q]) {
+      const int k = off / c->plane, j = (off - k * c->plane) / c->P, i = off - k * c->plane - j * c->P;
+      const int pos[3] = {i, j, k};
+      if (on_face(pos, pos)) return false;
+    }
+  }
+  for (int b = 0; b < c->nbox; ++b) {
+    const DevBox& bx = c->box[b];
+    if (bx.kind != FDTD_KIND_V || bx.npts <= 0) continue;
+    const int hi[3] = {bx.lo[0] + bx.ni - 1, bx.lo[1] + bx.nj - 1, bx.lo[2] + bx.nkk - 1};
+    if (on_face(bx.lo, hi)) return false;
+  }
+  return true;
+}
+
 // a main-kernel launch the runtime refused (kernels.hip: launch_main keeps the first one): reported once, as an error code
 static int launch_status(fdtd_ctx* c) {
   const int r = c->launch_failed;
@@ -833,8 +865,9 @@ static int phase_E(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
     launch_update_E(c, 0, 1, step, fused, false, s);
   }
   if (!c->mur_post_in_E) launch_mur(c, 1, s);   // post + apply (no-ops without Mur faces)
+  // no apply launch when update_H takes the candidates itself (step_loop decides: mur_direct_possible)
+  if (!(c->mur_direct && c->mur_post_in_E)) { launch_mur(c, 2, s); c->mur_direct = false; }
   c->mur_post_in_E = false;
-  launch_mur(c, 2, s);
   if (!fused) launch_post(c, FDTD_KIND_V, step, true, s);
   launch_dft(c, FDTD_KIND_V, step, s);
   if (multi && !rccl_inline(c)) HIPCK(c, hipEventRecord(c->ev_E, s));
@@ -857,7 +890,7 @@ static int phase_H(fdtd_ctx* c, bool multi, bool fused, ProfEvents* pe, int n) {
   if (!split) { int r = wait_halo(); if (r) return r; }
   // Mur scenes: the pre pass of step + 1 rides in this launch (it reads V only, which is final and not written here)
   launch_update_H(c, 0, split ? nk - 1 : nk, step, fused, s, fused && c->any_mur);
-  if (fused && c->any_mur && c->p.mur_nb > 0) c->mur_pre_step = step + 1;
+  if (fused && c->any_mur && (c->p.mur_nb > 0 || c->p.mur_direct)) c->mur_pre_step = step + 1;   // (mur_direct: the main blocks ran the pre pass)
   c->kev0 = c->kev1 = nullptr;
   if (split) {
     int r = wait_halo();
@@ -1070,7 +1103,9 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
     if (r) return r;
     c->p2p_primed = true;
   }
+  const bool direct = mur_direct_possible(c, multi, fused);
   for (int n = 0; n < nsteps; ++n) {
+    c->mur_direct = direct;
     int r = phase_E(c, multi, fused, pe, n);
     if (r) return r;
     if (multi && (r = exchange(c, FDTD_HALO_E_DOWN))) return r;
@@ -1078,6 +1113,7 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
     if (multi && (r = exchange(c, FDTD_HALO_H_UP))) return r;
     c->step++;
   }
+  c->mur_direct = false;
   if (fused && nsteps > 0) launch_post(c, FDTD_KIND_I, c->step - 1, false, c->stream);   // flush the last step's I-probes
   HIPCK(c, hipGetLastError());
   return launch_status(c);
@@ -1587,7 +1623,7 @@ int fdtd_schedule_info(fdtd_ctx* c, int32_t info[8]) {
   const bool steppable = c->have_op && (!multi || c->p.p2p || c->comm || c->link_lo || c->link_hi);
   const bool res = steppable && resident_active(c);
   const bool wf = steppable && !res && wavefront_active(c);
-  info[0] = !steppable ? 0 : res ? 1 : wf ? 1 : !c->any_mur ? 2 : (sources_fusable(c) && !multi && c->mur_fuse_post) ? 3 : 5;
+  info[0] = !steppable ? 0 : res ? 1 : wf ? 1 : !c->any_mur ? 2 : mur_direct_possible(c, multi, sources_fusable(c)) ? 2 : (sources_fusable(c) && !multi && c->mur_fuse_post) ? 3 : 5;
   info[1] = res ? -1 : wf ? wf_lag_for(c) : 0;
   info[2] = c->p.tys;
   info[3] = c->d.nk * c->p.nstrips * c->p.nbs;

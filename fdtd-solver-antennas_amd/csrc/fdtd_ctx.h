@@ -54,9 +54,14 @@ struct MurDevFace {
   int on, a, b, in;      // axis, local boundary index, inner index
   int ua, va, du, dv;    // in-face axes (u fast), extents
   float coeff;
-  float* st[2];
+  float* st[2];          // pre pass: V_inner - coeff * V_boundary (old values); same place and layout as cd
+  float* cd[2];          // post pass: st + coeff * V_inner (new values) = the boundary voltage the apply pass stores;
+  int co[2], cs;         // it lives behind the voltage array of its component: cd[t] = V[comp[t]] + co[t], row stride cs (P; x faces: ny)
   int comp[2];
 };
+// what an H thread needs of the faces to load candidates instead of boundary voltages (kernels.hip mur_load_V): a KERNEL ARGUMENT, so it
+// arrives with the other scalars — read through DevParams::mur it was a memory round trip in front of every wave's first field load
+struct MurH { int b[6]; int co[6][2]; int so[6][2]; float coeff[6]; /* b < 0: face off; co / so: offsets of cd / st from V[comp] */ };
 struct MurDev { MurDevFace f[6]; int bnd[6]; /* local boundary index per face, for the priority rule */ };
 
 struct DevParams {
@@ -125,12 +130,13 @@ struct DevParams {
   const MurDev* mur;         // device copy of the face table (null without Mur faces)
   int mur_nbx;               // blocks per (face, component) row
   int mur_nb;                // Mur blocks in THIS launch (0: none) — set by the launcher
+  int mur_direct;            // THIS launch: no apply pass ran — the H blocks and the pre pass take the candidates (kernels.hip mur_applied)
 };
 
 struct DevProbe { int kind, n; const int* off; const int8_t* comp; const float* w; double* series; };
 struct DevBox   { int kind, comp; int lo[3]; int ni, nj, nkk; double* acc; long npts; float* rec; /* recorder: [nsamples][npts] */ };
 
-struct MurFace { int on; float coeff; float* st[2]; int n; };
+struct MurFace { int on; float coeff; int n; };
 
 // host side of the resident schedule (resident.hip): tiling, per-tile source / probe-cell tables, the granule exchange buffer
 struct ResHost {
@@ -152,6 +158,7 @@ struct fdtd_ctx {
   int P = 0, plane = 0;
   size_t nloc = 0;               // nk*plane
   float* fieldbase[6] = {};      // allocations incl. ghosts
+  size_t mur_tail = 0;           // floats behind each voltage array: the Mur candidates (MurDevFace::cd)
   // P2P mailbox transport
   void* mbox = nullptr; size_t mbox_bytes = 0;     // my mailbox allocation
   bool mbox_fine = false;                          // fine-grained (system-coherent) device memory
@@ -207,9 +214,12 @@ struct fdtd_ctx {
   // mur
   MurFace mur[6] = {};
   bool any_mur = false;
+  MurH h_murh{};
   MurDev h_mur{}; MurDev* d_mur = nullptr;   // face table (built by fdtd_set_mur), host and device copy
   bool mur_fuse_post = true;                 // allow it ($FDTD_MUR_UNFUSED clears)
   bool mur_post_in_E = false;                // this launch of update_E runs the Mur post pass as well (set by phase_E)
+  bool mur_no_apply = true;                  // allow the schedule without an apply pass ($FDTD_MUR_APPLY_PASS=1 clears): api.hip mur_direct_possible
+  bool mur_direct = false;                   // this timestep: update_H reads the candidates itself and stores them (no k_mur apply launch)
   int64_t mur_pre_step = -1;                 // step whose Mur pre pass has already run (inside the previous update_H launch)
   // excitation
   float* sig = nullptr; int nsig = 0;

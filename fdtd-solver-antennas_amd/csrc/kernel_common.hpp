@@ -59,9 +59,10 @@ __device__ __forceinline__ bool xcd_position(const unsigned (&xs)[9], const unsi
   return true;
 }
 // strip-major order: v = (strip * planes + kk) * nbs + pb (fd_ps divides by planes * nbs)
-__device__ __forceinline__ bool decode_block_fd(const DevParams& p, const FastDiv& fd_ps, const FastDiv& fd_nbs, int rev, int& strip, int& kk, int& pb) {
+__device__ __forceinline__ bool decode_block_fd(const DevParams& p, const FastDiv& fd_ps, const FastDiv& fd_nbs, int rev, int& strip, int& kk, int& pb,
+                                                const unsigned first = 0u /* blocks in front of the main ones: a multiple of 8 */) {
   unsigned v;
-  if (!xcd_position(p.xs, blockIdx.x, rev, v)) return false;
+  if (!xcd_position(p.xs, blockIdx.x - first, rev, v)) return false;
   const unsigned s = fd_div(v, fd_ps);
   const unsigned rem = v - s * fd_ps.d;
   const unsigned k = fd_div(rem, fd_nbs);

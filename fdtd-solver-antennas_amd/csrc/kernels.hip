@@ -40,7 +40,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // K1: E half-step
 // ------------------------------------------------------------------------------------------------
-// Mur "post" pass (mode 1 of k_mur: S <- S + coeff * V_inner with the freshly updated V) for the face points whose inner
+// Mur "post" pass (mode 1 of k_mur: cd <- st + coeff * V_inner with the freshly updated V) for the face points whose inner
 // point this thread has just computed — the thread owns cells i0..i0+3 of row j in plane k and holds the new Vx, Vy, Vz.
 // A face point is touched by exactly one thread, so the (single) update per point is that of k_mur, bit for bit.
 // Two phases: the S values are LOADED with the field loads at the top of the kernel (PHASE 0) and updated + stored at its end
@@ -68,21 +68,21 @@ __device__ __forceinline__ void mur_post_inline(const DevParams& p, const MurDev
     const int a = fi >> 1;
     if (a == 2) {          // z faces: tangential x, y; s = j * nx + i (block-uniform test)
       if (k != f.in) continue;
-      float* const S0 = f.st[0] + j * p.nx + i0;
-      float* const S1 = f.st[1] + j * p.nx + i0;
+      float* const S0 = (PHASE == 0 ? f.st[0] : f.cd[0]) + j * p.P + i0;   // (rows of stride P, like a field plane)
+      float* const S1 = (PHASE == 0 ? f.st[1] : f.cd[1]) + j * p.P + i0;
       if (PHASE == 0) { mur_ld4(mv.z0, S0, n); mur_ld4(mv.z1, S1, n); }
       else { mur_st4(S0, f.coeff, vx, mv.z0, n); mur_st4(S1, f.coeff, vy, mv.z1, n); }
     } else if (a == 1) {   // y faces: comp[0] = z, comp[1] = x; s = k * nx + i
       if (j != f.in) continue;
-      float* const S0 = f.st[0] + k * p.nx + i0;
-      float* const S1 = f.st[1] + k * p.nx + i0;
+      float* const S0 = (PHASE == 0 ? f.st[0] : f.cd[0]) + k * p.P + i0;
+      float* const S1 = (PHASE == 0 ? f.st[1] : f.cd[1]) + k * p.P + i0;
       if (PHASE == 0) { mur_ld4(mv.y0, S0, n); mur_ld4(mv.y1, S1, n); }
       else { mur_st4(S0, f.coeff, vz, mv.y0, n); mur_st4(S1, f.coeff, vx, mv.y1, n); }
     } else {               // x faces: comp[0] = y, comp[1] = z; s = k * ny + j; one of the thread's four cells at most
       const int e = f.in - i0;
       if (e < 0 || e > 3) continue;
-      float* const S0 = f.st[0] + k * p.ny + j;
-      float* const S1 = f.st[1] + k * p.ny + j;
+      float* const S0 = (PHASE == 0 ? f.st[0] : f.cd[0]) + k * p.ny + j;
+      float* const S1 = (PHASE == 0 ? f.st[1] : f.cd[1]) + k * p.ny + j;
       if (PHASE == 0) { mv.x0 = *S0; mv.x1 = *S1; }
       else {   // four static cases: selecting the component with a computed index sends the vectors through scratch
         if (e == 0) { *S0 = __builtin_fmaf(f.coeff, vy.x, mv.x0); *S1 = __builtin_fmaf(f.coeff, vz.x, mv.x1); }
@@ -350,6 +350,133 @@ __global__ __launch_bounds__(FDTD_BLOCK, 4) void k_update_E_mur(const DevParams 
   body_E<COEF, PML, true, false, false, true>(p, strip, k_begin + kk, pb, step, s_lut, s_psi, s_xc, s_src, 0u, &m);
 }
 
+// ---- Mur without an apply pass (mur_direct) ----------------------------------------------------------------------------
+// The candidates cd (what the apply pass would store on the boundary nodes) live BEHIND each voltage array, in the same allocation
+// (build_mur_table): rows of stride P for y and z faces — a z face's candidates look like a field plane, a y face's like one row
+// per plane — and [k][j] for x faces.  So a thread that needs a boundary voltage loads the candidate by OFFSET from the same
+// base: no second pointer, and for whole rows / planes no extra load at all (mur_load_V).
+__device__ __forceinline__ void f4_put(float4& v, const int e, const float c) {
+  v.x = e == 0 ? c : v.x; v.y = e == 1 ? c : v.y; v.z = e == 2 ? c : v.z; v.w = e == 3 ? c : v.w;
+}
+// The nine voltage loads of an H thread (cells i0..i0+3 of row j in plane k; rows j+1, plane k+1 and cell i0+4 beside them) with
+// every node of a Mur face taken from the candidates.  z faces win over y faces over x faces (the apply order).  Rows, planes
+// and cells beyond the grid keep the addresses of the plain kernel (their values meet zero weights).  DEV: device-scope loads.
+// Two phases: mur_load_V issues the loads; mur_finish_V, called once the caller has issued its other loads as well (I, psi), puts
+// the x-face candidates into their cells — it is the first use of the loaded values, i.e. where the wave waits.
+struct MurX { float c_vy, c_vz, c_vzjp, c_vykp; };   // the x-face candidates of the thread's boundary cell
+__device__ __forceinline__ void mur_finish_V(const DevParams& p, const MurH& m, const MurX& x, const int k, const int j, const int i0,
+                                             float4& vy, float4& vz, float4& vz_jp, float4& vy_kp) {
+  // which cell, and whether a later face has the node (then the load took that face's candidates already): worked out again
+  // rather than kept from mur_load_V — compares against scalars cost less than registers here
+  int e = -1;
+  if (m.b[0] == 0 && i0 == 0) e = 0;
+  if (m.b[1] >= 0 && (unsigned)(m.b[1] - i0) < 4u) e = m.b[1] - i0;
+  const bool zk = k == m.b[4] || k == m.b[5], zk1 = (k + 1 == m.b[4] || k + 1 == m.b[5]) && k + 1 < p.nk;
+  const bool yj = j == m.b[2] || j == m.b[3], yj1 = (j + 1 == m.b[2] || j + 1 == m.b[3]) && j + 1 < p.ny;
+  f4_put(vy, zk ? -1 : e, x.c_vy);
+  f4_put(vz, yj ? -1 : e, x.c_vz);
+  f4_put(vz_jp, (yj1 || j + 1 >= p.ny) ? -1 : e, x.c_vzjp);
+  f4_put(vy_kp, (zk1 || k + 1 >= p.nk) ? -1 : e, x.c_vykp);
+}
+template <bool DEV>
+__device__ __forceinline__ MurX mur_load_V(const DevParams& p, const int k, const int j, const int i0, const unsigned uo, const bool ip_load,
+                                           float4& vx, float4& vy, float4& vz, float4& vz_jp, float4& vx_jp, float4& vy_kp, float4& vx_kp,
+                                           float& vz_ip, float& vy_ip, const MurH& m) {
+  const unsigned P = (unsigned)p.P, rj = (unsigned)(j * p.P + i0), rk = (unsigned)(k * p.P + i0), xrow = (unsigned)(k * p.ny + j);
+  const bool jp = j + 1 < p.ny, kp = k + 1 < p.nk;
+  int zx = -1, zy = -1, zx1 = -1, zy1 = -1;   // z faces: candidate offsets of Vx, Vy for plane k / plane k + 1 (block-uniform)
+  int yz = -1, yx = -1, yz1 = -1, yx1 = -1;   // y faces: of Vz, Vx for row j / row j + 1
+  MurX x;
+#pragma unroll
+  for (int g = 4; g < 6; ++g) {   // (a face that is off has b = -1: never equal to a plane, row or cell index)
+    if (k == m.b[g]) { zx = m.co[g][0]; zy = m.co[g][1]; }
+    if (k + 1 == m.b[g]) { zx1 = m.co[g][0]; zy1 = m.co[g][1]; }
+  }
+#pragma unroll
+  for (int g = 2; g < 4; ++g) {
+    if (j == m.b[g]) { yz = m.co[g][0]; yx = m.co[g][1]; }
+    if (j + 1 == m.b[g]) { yz1 = m.co[g][0]; yx1 = m.co[g][1]; }
+  }
+  // x faces: one of the thread's four cells at most (nx >= 6); its four candidates are loads of their own, issued first
+  int e = -1, cxy = 0, cxz = 0;
+  if (m.b[0] == 0 && i0 == 0) { e = 0; cxy = m.co[0][0]; cxz = m.co[0][1]; }
+  if (m.b[1] >= 0 && (unsigned)(m.b[1] - i0) < 4u) { e = m.b[1] - i0; cxy = m.co[1][0]; cxz = m.co[1][1]; }
+  const bool xh_ip = m.b[1] >= 0 && i0 + 4 == m.b[1];
+  const unsigned o_vx = zx >= 0 ? zx + rj : yx >= 0 ? yx + rk : uo;
+  const unsigned o_vy = zy >= 0 ? zy + rj : uo;
+  const unsigned o_vz = yz >= 0 ? yz + rk : uo;
+  const unsigned o_vzjp = (yz1 >= 0 && jp) ? yz1 + rk : uo + P;
+  const unsigned o_vxjp = (zx >= 0 && jp) ? zx + rj + P : (yx1 >= 0 && jp) ? yx1 + rk : uo + P;
+  const unsigned o_vykp = (zy1 >= 0 && kp) ? zy1 + rj : uo + (unsigned)p.plane;
+  const unsigned o_vxkp = (zx1 >= 0 && kp) ? zx1 + rj : (yx >= 0 && kp) ? yx + rk + P : uo + (unsigned)p.plane;
+  const bool in = i0 + 4 < p.nx;
+  unsigned o_vzip = (in && yz >= 0) ? yz + rk + 4u : xh_ip ? m.co[1][1] + xrow : uo + 4u;
+  unsigned o_vyip = (in && zy >= 0) ? zy + rj + 4u : xh_ip ? m.co[1][0] + xrow : uo + 4u;
+  if (!ip_load) o_vzip = o_vyip = (unsigned)__builtin_amdgcn_readfirstlane((int)uo);   // (lane shift: the value comes from the neighbour lane)
+  float c_vy = 0.f, c_vz = 0.f, c_vzjp = 0.f, c_vykp = 0.f;
+  if (DEV) {
+    const DevRsrc b0 = dev_buf(p.V[0]), b1 = dev_buf(p.V[1]), b2 = dev_buf(p.V[2]);
+    if (e >= 0) {
+      c_vy = ldb1_dev(b1, (cxy + xrow) << 2, 0u); c_vz = ldb1_dev(b2, (cxz + xrow) << 2, 0u);
+      c_vzjp = ldb1_dev(b2, (cxz + xrow + (jp ? 1u : 0u)) << 2, 0u); c_vykp = ldb1_dev(b1, (cxy + xrow + (kp ? (unsigned)p.ny : 0u)) << 2, 0u);
+    }
+    vx = ldb4_dev(b0, o_vx << 2, 0u); vy = ldb4_dev(b1, o_vy << 2, 0u); vz = ldb4_dev(b2, o_vz << 2, 0u);
+    vz_jp = ldb4_dev(b2, o_vzjp << 2, 0u); vx_jp = ldb4_dev(b0, o_vxjp << 2, 0u);
+    vy_kp = ldb4_dev(b1, o_vykp << 2, 0u); vx_kp = ldb4_dev(b0, o_vxkp << 2, 0u);
+    vz_ip = ldb1_dev(b2, o_vzip << 2, 0u); vy_ip = ldb1_dev(b1, o_vyip << 2, 0u);
+  } else {
+    if (e >= 0) {
+      c_vy = ldo1(p.V[1], cxy + xrow); c_vz = ldo1(p.V[2], cxz + xrow);
+      c_vzjp = ldo1(p.V[2], cxz + xrow + (jp ? 1u : 0u)); c_vykp = ldo1(p.V[1], cxy + xrow + (kp ? (unsigned)p.ny : 0u));
+    }
+    vx = ldo4(p.V[0], o_vx); vy = ldo4(p.V[1], o_vy); vz = ldo4(p.V[2], o_vz);
+    vz_jp = ldo4(p.V[2], o_vzjp); vx_jp = ldo4(p.V[0], o_vxjp);
+    vy_kp = ldo4(p.V[1], o_vykp); vx_kp = ldo4(p.V[0], o_vxkp);
+    vz_ip = ldo1(p.V[2], o_vzip); vy_ip = ldo1(p.V[1], o_vyip);
+  }
+  x.c_vy = c_vy; x.c_vz = c_vz; x.c_vzjp = c_vzjp; x.c_vykp = c_vykp;
+  return x;
+}
+
+__device__ __forceinline__ float f4_get(const float4& v, const int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+__device__ __forceinline__ float4 mur_pre4(const float c, const float4& vb, const float4& vi) {   // k_mur mode 0, four cells
+  return make_float4(__builtin_fmaf(-c, vb.x, vi.x), __builtin_fmaf(-c, vb.y, vi.y), __builtin_fmaf(-c, vb.z, vi.z), __builtin_fmaf(-c, vb.w, vi.w));
+}
+// What is left of the apply pass and the pre pass of the next timestep, done by the H threads that hold the values anyway (all
+// of them "applied": mur_load_V): (i) a thread whose own cells lie on a face stores their boundary voltages — nobody in this
+// launch reads them there, the next update_E does; (ii) st = V_inner - coeff * V_boundary by the thread that has both: for a
+// lower face the one on the boundary (its j + 1 / k + 1 neighbour is the inner node), for an upper face the one on the inner
+// node.  As a pass of its own (one thread per face point, 12 rows of blocks behind the main ones) this cost 2.4 / 5.6 / 11.5 us
+// on 200x200x40 / 300x300x60 / 400x400x80; here it is a few stores of the boundary threads.
+__device__ __forceinline__ void mur_pre_store(const DevParams& p, const MurH& m, const int k, const int j, const int i0, const unsigned uo,
+                                              const float4& vx, const float4& vy, const float4& vz, const float4& vz_jp, const float4& vx_jp,
+                                              const float4& vy_kp, const float4& vx_kp, const float vz_ip, const float vy_ip) {
+#ifdef FDTD_DIAG_MUR_NO_PRE   // timing experiments only (tools/build_variant.sh): what the main blocks cost without this — wrong fields
+  return;
+#endif
+  const unsigned rj = (unsigned)(j * p.P + i0), rk = (unsigned)(k * p.P + i0), xrow = (unsigned)(k * p.ny + j);
+  // (which faces the thread touches is worked out again rather than kept from mur_load_V: compares against scalars cost less than registers here)
+  const bool onz = k == m.b[4] || k == m.b[5], ony = j == m.b[2] || j == m.b[3];
+  const bool onx = (m.b[0] == 0 && i0 == 0) || (m.b[1] >= 0 && (unsigned)(m.b[1] - i0) < 4u);
+  if (onz || ony) sto4s(0, p.V[0], uo, vx);
+  if (onz || onx) sto4s(0, p.V[1], uo, vy);
+  if (ony || onx) sto4s(0, p.V[2], uo, vz);
+  if (k == m.b[4]) { sto4s(0, p.V[0], m.so[4][0] + rj, mur_pre4(m.coeff[4], vx, vx_kp)); sto4s(0, p.V[1], m.so[4][1] + rj, mur_pre4(m.coeff[4], vy, vy_kp)); }
+  if (k + 1 == m.b[5]) { sto4s(0, p.V[0], m.so[5][0] + rj, mur_pre4(m.coeff[5], vx_kp, vx)); sto4s(0, p.V[1], m.so[5][1] + rj, mur_pre4(m.coeff[5], vy_kp, vy)); }
+  if (j == m.b[2]) { sto4s(0, p.V[2], m.so[2][0] + rk, mur_pre4(m.coeff[2], vz, vz_jp)); sto4s(0, p.V[0], m.so[2][1] + rk, mur_pre4(m.coeff[2], vx, vx_jp)); }
+  if (j + 1 == m.b[3]) { sto4s(0, p.V[2], m.so[3][0] + rk, mur_pre4(m.coeff[3], vz_jp, vz)); sto4s(0, p.V[0], m.so[3][1] + rk, mur_pre4(m.coeff[3], vx_jp, vx)); }
+  if (m.b[0] == 0 && i0 == 0) {
+    p.V[1][m.so[0][0] + xrow] = __builtin_fmaf(-m.coeff[0], vy.x, vy.y);
+    p.V[2][m.so[0][1] + xrow] = __builtin_fmaf(-m.coeff[0], vz.x, vz.y);
+  }
+  const int ei = m.b[1] - 1 - i0;   // the inner node of the upper x face among the thread's cells
+  if (m.b[1] >= 0 && (unsigned)ei < 4u) {
+    const float by = ei < 3 ? f4_get(vy, ei + 1) : vy_ip, bz = ei < 3 ? f4_get(vz, ei + 1) : vz_ip;
+    p.V[1][m.so[1][0] + xrow] = __builtin_fmaf(-m.coeff[1], by, f4_get(vy, ei));
+    p.V[2][m.so[1][1] + xrow] = __builtin_fmaf(-m.coeff[1], bz, f4_get(vz, ei));
+  }
+}
+
 // Mur "pre" pass (mode 0 of k_mur) of one block: S = V_inner - coeff * V_boundary on the values BEFORE the next E update.
 // e = block index among the Mur blocks of the launch: (face * 2 + tangential component) * mur_nbx + block within the face.
 __device__ __forceinline__ void mur_pre_block(const DevParams& p, const unsigned e) {
@@ -367,15 +494,17 @@ __device__ __forceinline__ void mur_pre_block(const DevParams& p, const unsigned
   const float* V = p.V[f.comp[t]];
   const int ob = pos[0] + pos[1] * p.P + pos[2] * p.plane;
   const int oi = ob + (f.in - f.b) * stride[f.a];
-  f.st[t][s] = __builtin_fmaf(-f.coeff, V[ob], V[oi]);
+  f.st[t][iv * f.cs + iu] = __builtin_fmaf(-f.coeff, V[ob], V[oi]);
 }
 
 // ------------------------------------------------------------------------------------------------
 // K2: H half-step
 // ------------------------------------------------------------------------------------------------
-template <bool RAW, bool PML, bool P2P, bool WF, bool MULTI = false>
+// MUR: Mur faces without an apply pass — the block takes the boundary voltages it reads from the candidates (mur_sub4).
+template <bool RAW, bool PML, bool P2P, bool WF, bool MULTI = false, bool MUR = false>
 __device__ __forceinline__ void body_H(const DevParams& p, const int strip, const int k, const int pb, const long long step,
-                                       float4* const s_psi, float* const s_xc, const unsigned wf_target, const unsigned back_target = 0u) {
+                                       float4* const s_psi, float* const s_xc, const unsigned wf_target, const unsigned back_target = 0u,
+                                       const MurH* const mh = nullptr) {
   static_assert(!(MULTI && P2P), "several timesteps per launch: single slabs only");
   int j = 0, i0 = 0;
   const bool staged = PML && FDTD_PSI_STAGE;
@@ -393,17 +522,22 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
   float4 vx, vy, vz, vz_jp, vx_jp, ix, iy, iz;
   float4 vy_kp = make_float4(0.f, 0.f, 0.f, 0.f), vx_kp = vy_kp;
   float vz_ip, vy_ip;
+  MurX mx;
   // (lane shift) the thread whose right-hand neighbour thread is in another wave, or does not exist (end of the strip-plane), loads
   constexpr bool LS = FDTD_LANE_SHIFT && LANE_SHIFT_FITS(WF, MULTI);
   const bool ip_load = !LS || (threadIdx.x & 63u) == 63u ||
                        pb * FDTD_BLOCK + (int)threadIdx.x + 1 >= min(p.tys, p.ny - strip * p.tys) * p.P4;
   if (!WF) {
+    if (MUR) {
+      mx = mur_load_V<false>(p, k, j, i0, uo, ip_load, vx, vy, vz, vz_jp, vx_jp, vy_kp, vx_kp, vz_ip, vy_ip, *mh);
+    } else {
     vx = ldo4(p.V[0], uo); vy = ldo4(p.V[1], uo); vz = ldo4(p.V[2], uo);
     vz_jp = ldo4(p.V[2] + p.P, uo); vx_jp = ldo4(p.V[0] + p.P, uo);   // neighbour displacements in the scalar bases: one offset VGPR
     if (!dep_in) { vy_kp = ldo4(p.V[1] + p.plane, uo); vx_kp = ldo4(p.V[0] + p.plane, uo); }
     {
       const unsigned ue = ip_load ? uo : (unsigned)__builtin_amdgcn_readfirstlane((int)uo);
       vz_ip = ldo1(p.V[2] + 4, ue); vy_ip = ldo1(p.V[1] + 4, ue);
+    }
     }
     ix = ldo4(p.I[0], uo); iy = ldo4(p.I[1], uo); iz = ldo4(p.I[2], uo);
     if (staged)
@@ -444,10 +578,12 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
              0x10000000u | (WF ? 0x20000000u : 0u) | ((unsigned)strip << 14) | (unsigned)pb);   // who: H half-step (bit 28)
   }
 
+  if (MUR) mur_finish_V(p, *mh, mx, k, j, i0, vy, vz, vz_jp, vy_kp);
   if (LS) {
     const float zn = lane_next(vz.x), yn = lane_next(vy.x);
     if (!ip_load) { vz_ip = zn; vy_ip = yn; }
   }
+  if (MUR && valid) mur_pre_store(p, *mh, k, j, i0, uo, vx, vy, vz, vz_jp, vx_jp, vy_kp, vx_kp, vz_ip, vy_ip);
   float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);
   float4 dy1 = sub4(vx, vx_kp);
   float4 dy2 = make_float4(vz.x - vz.y, vz.y - vz.z, vz.z - vz.w, vz.w - vz_ip);
@@ -520,16 +656,16 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
   if (pub) wf_publish(p, p.wf_flagsH, k, strip, pb, wf_target);
 }
 
-template <bool RAW, bool PML, bool P2P>
+template <bool RAW, bool PML, bool P2P, bool MUR = false>
 __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : FDTD_H_MINBLOCKS) void k_update_H(const DevParams p, const int k_begin, const FastDiv fd_ps,
-                                                                            const long long step, const int extra, const unsigned nb_main) {
+                                                                            const long long step, const int extra, const unsigned nb_main, const MurH mh) {
   // CPML psi staging (LDS-DMA, 16 KiB); the probe block borrows it for its reduction
   __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : FDTD_BLOCK / 2];
   __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
   double* const s_red = reinterpret_cast<double*>(s_psi);
   if (extra && blockIdx.x >= gridDim.x - (unsigned)extra) {   // the extra blocks at the end of the grid:
     const unsigned e = blockIdx.x - (gridDim.x - (unsigned)extra);
-    if (e < (unsigned)p.mur_nb) mur_pre_block(p, e);          // Mur pre pass of the next step (V is final, H not read)
+    if (e < (unsigned)p.mur_nb) mur_pre_block(p, e);          // Mur pre pass of the next step (V is final, H not read); MUR: the main blocks do it
     else probe_block(p, FDTD_KIND_V, step, s_red);            // last one: V-probes of this step
     return;
   }
@@ -540,7 +676,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
     if (!decode_block_fd(p, fd_ps, p.fd_nbs, p.sweep_rev, strip, kk, pb)) return;
     k = k_begin + kk;
   }
-  body_H<RAW, PML, P2P, false>(p, strip, k, pb, step, s_psi, s_xc, 0u);
+  body_H<RAW, PML, P2P, false, false, MUR>(p, strip, k, pb, step, s_psi, s_xc, 0u, 0u, &mh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -659,11 +795,11 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_mur(const DevParams p, const Mur
   float* V = p.V[comp];
   const int ob = pos[0] + pos[1] * p.P + pos[2] * p.plane;
   const int oi = ob + (f.in - f.b) * stride[f.a];
-  float* S = f.st[t];
+  const int ci = iv * f.cs + iu;   // st and cd: rows of stride cs (P; x faces: ny)
   if (mode == 0) {
-    S[s] = __builtin_fmaf(-f.coeff, V[ob], V[oi]);
+    f.st[t][ci] = __builtin_fmaf(-f.coeff, V[ob], V[oi]);
   } else if (mode == 1) {
-    S[s] = __builtin_fmaf(f.coeff, V[oi], S[s]);
+    f.cd[t][ci] = __builtin_fmaf(f.coeff, V[oi], f.st[t][ci]);
   } else {
     // faces are applied in order 0..5 by the reference order; a later face wins on shared edges
     for (int g = fi + 1; g < 6; ++g) {
@@ -671,7 +807,7 @@ __global__ __launch_bounds__(FDTD_BLOCK) void k_mur(const DevParams p, const Mur
       const int ga = g >> 1;
       if (ga != comp && pos[ga] == m.bnd[g]) return;
     }
-    V[ob] = S[s];
+    V[ob] = f.cd[t][ci];
   }
 }
 
@@ -1176,13 +1312,14 @@ static void launch_H2(fdtd_ctx* c, int k_begin, int nkr, long long step, int ext
     const unsigned nb_main = (unsigned)c->p.nstrips * (unsigned)(nkr - 1) * (unsigned)c->p.nbs;
     set_xcd_shares(c, 0, nkr - 1);
     const dim3 grid(c->p.xgrid + (unsigned)(c->p.nstrips * c->p.nbs) + (unsigned)extra);
-    launch_main(c, k_update_H<RAW, PML, true>, grid, pad, cap, s, c->p, 0, fd_ps, step, extra, nb_main);
+    launch_main(c, k_update_H<RAW, PML, true>, grid, pad, cap, s, c->p, 0, fd_ps, step, extra, nb_main, c->h_murh);
     return;
   }
   set_xcd_shares(c, k_begin, nkr);
   const dim3 grid(c->p.xgrid + (unsigned)extra);
   const FastDiv fd_ps = make_fastdiv((unsigned)nkr * (unsigned)c->p.nbs);
-  launch_main(c, k_update_H<RAW, PML, false>, grid, pad, cap, s, c->p, k_begin, fd_ps, step, extra, 0u);
+  if (c->p.mur_direct) launch_main(c, k_update_H<RAW, PML, false, true>, grid, pad, cap, s, c->p, k_begin, fd_ps, step, extra, 0u, c->h_murh);
+  else launch_main(c, k_update_H<RAW, PML, false>, grid, pad, cap, s, c->p, k_begin, fd_ps, step, extra, 0u, c->h_murh);
 }
 
 void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool probe_block, hipStream_t s, bool mur_pre) {
@@ -1191,6 +1328,8 @@ void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool p
   // extra blocks behind the main ones: [Mur pre pass of the next step (12 rows of mur_nbx blocks)] [probe block]; the Mur
   // blocks only ride along when the probe block does (the kernel tells them apart by their distance from the end)
   c->p.mur_nb = (mur_pre && probe_block && c->any_mur && c->d_mur) ? 12 * c->p.mur_nbx : 0;
+  c->p.mur_direct = (c->mur_direct && c->p.mur_nb > 0) ? 1 : 0;   // (phase_E skipped the apply launch on the same condition)
+  if (c->p.mur_direct) c->p.mur_nb = 0;                           // no apply pass: the main blocks store boundary voltages and st themselves
   const int extra = (probe_block ? 1 : 0) + c->p.mur_nb;
   if (c->raw_op) {
     if (c->have_cpml) launch_H2<true, true>(c, k_begin, nkr, step, extra, s);
@@ -1368,6 +1507,8 @@ int build_mur_table(fdtd_ctx* c) {
   m = MurDev{};
   const int dim[3] = {c->p.nx, c->p.ny, c->p.nk};
   int maxpts = 1;
+  size_t tail_next[3];
+  for (int q = 0; q < 3; ++q) tail_next[q] = (size_t)(c->p.nk + 1) * c->p.plane;   // first float behind the upper ghost plane (fdtd_create: mur_tail)
   for (int f = 0; f < 6; ++f) {
     const int a = f / 2, hi = f & 1;
     MurDevFace& d = m.f[f];
@@ -1382,10 +1523,21 @@ int build_mur_table(fdtd_ctx* c) {
     d.va = pa < qa ? qa : pa;
     d.du = dim[d.ua]; d.dv = dim[d.va];
     d.coeff = c->mur[f].coeff;
-    d.st[0] = c->mur[f].st[0]; d.st[1] = c->mur[f].st[1];
     d.comp[0] = pa; d.comp[1] = qa;
+    d.cs = a == 0 ? dim[1] : c->p.P;
+    for (int t = 0; t < 2; ++t) {   // candidates: behind the voltage array of their component (mur_load_V), 16-byte aligned pieces
+      const int comp = d.comp[t];
+      const size_t n = a == 0 ? (size_t)dim[2] * dim[1] : (size_t)(a == 1 ? dim[2] : dim[1]) * c->p.P;
+      d.co[t] = (int)tail_next[comp];
+      d.cd[t] = c->p.V[comp] + tail_next[comp];
+      tail_next[comp] += (n + 3) & ~(size_t)3;
+      c->h_murh.so[f][t] = (int)tail_next[comp];   // st: same layout, right behind
+      d.st[t] = c->p.V[comp] + tail_next[comp];
+      tail_next[comp] += (n + 3) & ~(size_t)3;
+    }
     if (d.on && d.du * d.dv > maxpts) maxpts = d.du * d.dv;
   }
+  for (int f = 0; f < 6; ++f) { c->h_murh.b[f] = m.f[f].on ? m.f[f].b : -1; c->h_murh.co[f][0] = m.f[f].co[0]; c->h_murh.co[f][1] = m.f[f].co[1]; c->h_murh.coeff[f] = m.f[f].coeff; }
   c->p.mur_nbx = (maxpts + FDTD_BLOCK - 1) / FDTD_BLOCK;
   c->p.mur = nullptr; c->p.mur_nb = 0;
   c->mur_pre_step = -1;

@@ -29,14 +29,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = "fdtd-solver-antennas_amd"
-ENV_KNOBS = ("FDTD_TYS", "FDTD_WF_MULTI", "FDTD_XCD_ADAPT", "FDTD_WF_LAG", "FDTD_RESIDENT", "FDTD_RES_CHUNK")
+ENV_KNOBS = ("FDTD_TYS", "FDTD_WF_MULTI", "FDTD_XCD_ADAPT", "FDTD_WF_LAG", "FDTD_RESIDENT", "FDTD_RES_CHUNK", "FDTD_MUR_APPLY_PASS")
 
 
 def _mod(name):
     return importlib.import_module(PKG + "." + name)
 
 
-def draw_case(rng):
+def draw_case(rng, mur=False):
     """One case as a plain dict (printable, reproducible from --seed / --only)."""
     nx = int(rng.choice([rng.integers(8, 40), rng.integers(40, 141), 4 * rng.integers(3, 30) + 1, 4 * rng.integers(3, 30)]))
     ny = int(rng.choice([rng.integers(8, 30), rng.integers(30, 121)]))
@@ -50,6 +50,10 @@ def draw_case(rng):
         kinds = [str(rng.choice(["PEC", "MUR", "CPML"])) for _ in range(6)]
     if rng.random() < 0.12:      # now and then a grid of a few thousand blocks per half-step (several blocks per CU, every XCD share long)
         nx, ny, nz = int(rng.integers(150, 260)), int(rng.integers(120, 220)), int(rng.integers(24, 44))
+    if mur:      # --mur: every case has Mur faces (all six, or mixed with PEC / CPML) and mostly runs on the launch-per-half-step schedules
+        kinds = ["MUR"] * 6 if rng.random() < 0.5 else [str(rng.choice(["PEC", "MUR", "MUR", "CPML"])) for _ in range(6)]
+        if "MUR" not in kinds:
+            kinds[int(rng.integers(0, 6))] = "MUR"
     cells_max = max(2, min(12, (min(nx, ny, nz) - 8) // 2))
     cells = int(rng.integers(2, cells_max + 1))
     has_mur = "MUR" in kinds
@@ -59,6 +63,11 @@ def draw_case(rng):
     # every grid that does not fit the chip), and the resident launches are cut short now and then
     if sched == "auto" and rng.random() < 0.5:
         env["FDTD_RESIDENT"] = "0"
+    if mur:
+        if sched != "resident" and rng.random() < 0.8:
+            env["FDTD_RESIDENT"] = "0"
+        if rng.random() < 0.25:      # the apply pass as a launch of its own (three launches per timestep) instead of inside update_H (two)
+            env["FDTD_MUR_APPLY_PASS"] = "1"
     if rng.random() < 0.3:
         env["FDTD_RES_CHUNK"] = str(int(rng.choice([1, 2, 7, 33])))
     if rng.random() < 0.4:
@@ -231,11 +240,11 @@ def load_libs():
     return capi.load_hip_library(), capi.bind(ctypes.CDLL(so))
 
 
-def run_batch(ncases, seed, hip, oracle, only=None, log=print, slabs=False):
+def run_batch(ncases, seed, hip, oracle, only=None, log=print, slabs=False, mur=False):
     rng = np.random.default_rng(seed)
     failed = []
     for n in range(ncases):
-        case = (draw_slab_case if slabs else draw_case)(rng)
+        case = draw_slab_case(rng) if slabs else draw_case(rng, mur)
         if only is not None and n != only:
             continue
         t0 = time.perf_counter()
@@ -268,9 +277,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=None)
     ap.add_argument("--slabs", action="store_true", help="decomposed runs: 2 ... 6 P2P slabs in one process against one slab on the oracle")
+    ap.add_argument("--mur", action="store_true", help="every case with Mur faces, mostly on the two / three launches per timestep")
     args = ap.parse_args()
     hip, oracle = load_libs()
-    failed = run_batch(args.cases, args.seed, hip, oracle, args.only, log=lambda s: print(s, flush=True), slabs=args.slabs)
+    failed = run_batch(args.cases, args.seed, hip, oracle, args.only, log=lambda s: print(s, flush=True), slabs=args.slabs, mur=args.mur)
     print(f"{len(failed)} failing case(s) of {args.cases} (seed {args.seed})", flush=True)
     sys.exit(1 if failed else 0)
 
