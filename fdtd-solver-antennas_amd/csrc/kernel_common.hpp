@@ -339,9 +339,11 @@ __device__ __forceinline__ void apply_staged(const SrcStage& st, int n, int comp
 }
 
 // value[step] = sum_e w[e]*field[e] for every probe of `kind` (one block, fixed reduction tree)
-__device__ __forceinline__ void probe_block(const DevParams& p, const int kind, const long long step, double* red) {
+// only >= 0: that probe alone (the update kernels carry one such block per probe: a multi-port scene has several probes of a thousand
+// cells each, and ONE block walking through them all outlasted the main blocks — 143x129x89 with four ports: 10 us of a 38 us timestep)
+__device__ __forceinline__ void probe_block(const DevParams& p, const int kind, const long long step, double* red, const int only = -1) {
   if (step < 0 || step >= p.max_steps) return;
-  for (int q = 0; q < p.nprobe; ++q) {
+  for (int q = only >= 0 ? only : 0; q < (only >= 0 ? only + 1 : p.nprobe); ++q) {
     const DevProbe pr = p.probes[q];
     if (pr.kind != kind) continue;
     double s = 0.0;

@@ -43,48 +43,42 @@ namespace {
 // Mur "post" pass (mode 1 of k_mur: cd <- st + coeff * V_inner with the freshly updated V) for the face points whose inner
 // point this thread has just computed — the thread owns cells i0..i0+3 of row j in plane k and holds the new Vx, Vy, Vz.
 // A face point is touched by exactly one thread, so the (single) update per point is that of k_mur, bit for bit.
-// Two phases: the S values are LOADED with the field loads at the top of the kernel (PHASE 0) and updated + stored at its end
-// (PHASE 1); loaded at the end they were a second, exposed memory round trip (update_E + post 8.7 us on the reference's
-// 56x55x50 scene: exactly the 4.9 + 4.0 us of the two separate launches).  Per axis a thread lies next to at most one face
-// (the host takes the separate launch for grids under 5 nodes along an axis).
-struct MurVals { float4 z0, z1, y0, y1; float x0, x1; };
-__device__ __forceinline__ void mur_ld4(float4& r, const float* S, const int n) {
-  r.x = S[0]; r.y = n > 1 ? S[1] : 0.f; r.z = n > 2 ? S[2] : 0.f; r.w = n > 3 ? S[3] : 0.f;
-}
-__device__ __forceinline__ void mur_st4(float* S, const float c, const float4& v, const float4& s, const int n) {
-  S[0] = __builtin_fmaf(c, v.x, s.x);
-  if (n > 1) S[1] = __builtin_fmaf(c, v.y, s.y);
-  if (n > 2) S[2] = __builtin_fmaf(c, v.z, s.z);
-  if (n > 3) S[3] = __builtin_fmaf(c, v.w, s.w);
+// Two phases.  The st values of the x faces are LOADED with the field loads at the top of the kernel (PHASE 0) and used at its end
+// (PHASE 1): every wave holds a cell next to an x face, and loaded at the end they were a second, exposed memory round trip for
+// all of them.  Those of the y and z faces — whole rows and planes, i.e. few waves — are loaded where they are used: kept from
+// the top they were 16 more registers in EVERY wave (82 ... 90 VGPRs: five waves per SIMD where the plain kernel has seven).
+// st and cd rows have stride P and zero pad cells, like field rows: whole float4 accesses.  Per axis a thread lies next to at
+// most one face (the host takes the separate launch for grids under 5 nodes along an axis).
+struct MurVals { float x0, x1; };
+__device__ __forceinline__ float4 mur_post4(const float c, const float4& v, const float4& s) {   // k_mur mode 1, four cells
+  return make_float4(__builtin_fmaf(c, v.x, s.x), __builtin_fmaf(c, v.y, s.y), __builtin_fmaf(c, v.z, s.z), __builtin_fmaf(c, v.w, s.w));
 }
 template <int PHASE>
 __device__ __forceinline__ void mur_post_inline(const DevParams& p, const MurDev& m, const int k, const int j, const int i0, MurVals& mv,
                                                 const float4& vx, const float4& vy, const float4& vz) {
-  const int n = p.nx - i0;   // cells of the thread's group inside the grid
 #pragma unroll
   for (int fi = 0; fi < 6; ++fi) {
     const MurDevFace& f = m.f[fi];
     if (!f.on) continue;
     const int a = fi >> 1;
-    if (a == 2) {          // z faces: tangential x, y; s = j * nx + i (block-uniform test)
-      if (k != f.in) continue;
-      float* const S0 = (PHASE == 0 ? f.st[0] : f.cd[0]) + j * p.P + i0;   // (rows of stride P, like a field plane)
-      float* const S1 = (PHASE == 0 ? f.st[1] : f.cd[1]) + j * p.P + i0;
-      if (PHASE == 0) { mur_ld4(mv.z0, S0, n); mur_ld4(mv.z1, S1, n); }
-      else { mur_st4(S0, f.coeff, vx, mv.z0, n); mur_st4(S1, f.coeff, vy, mv.z1, n); }
-    } else if (a == 1) {   // y faces: comp[0] = z, comp[1] = x; s = k * nx + i
-      if (j != f.in) continue;
-      float* const S0 = (PHASE == 0 ? f.st[0] : f.cd[0]) + k * p.P + i0;
-      float* const S1 = (PHASE == 0 ? f.st[1] : f.cd[1]) + k * p.P + i0;
-      if (PHASE == 0) { mur_ld4(mv.y0, S0, n); mur_ld4(mv.y1, S1, n); }
-      else { mur_st4(S0, f.coeff, vz, mv.y0, n); mur_st4(S1, f.coeff, vx, mv.y1, n); }
-    } else {               // x faces: comp[0] = y, comp[1] = z; s = k * ny + j; one of the thread's four cells at most
+    if (a == 2) {          // z faces: tangential x, y; rows j of a plane (block-uniform test)
+      if (PHASE == 0 || k != f.in) continue;
+      const int o = j * p.P + i0;
+      st4(f.cd[0] + o, mur_post4(f.coeff, vx, ld4(f.st[0] + o)));
+      st4(f.cd[1] + o, mur_post4(f.coeff, vy, ld4(f.st[1] + o)));
+    } else if (a == 1) {   // y faces: comp[0] = z, comp[1] = x; one row per plane
+      if (PHASE == 0 || j != f.in) continue;
+      const int o = k * p.P + i0;
+      st4(f.cd[0] + o, mur_post4(f.coeff, vz, ld4(f.st[0] + o)));
+      st4(f.cd[1] + o, mur_post4(f.coeff, vx, ld4(f.st[1] + o)));
+    } else {               // x faces: comp[0] = y, comp[1] = z; [k][j]; one of the thread's four cells at most
       const int e = f.in - i0;
       if (e < 0 || e > 3) continue;
-      float* const S0 = (PHASE == 0 ? f.st[0] : f.cd[0]) + k * p.ny + j;
-      float* const S1 = (PHASE == 0 ? f.st[1] : f.cd[1]) + k * p.ny + j;
-      if (PHASE == 0) { mv.x0 = *S0; mv.x1 = *S1; }
+      const int o = k * p.ny + j;
+      if (PHASE == 0) { mv.x0 = f.st[0][o]; mv.x1 = f.st[1][o]; }
       else {   // four static cases: selecting the component with a computed index sends the vectors through scratch
+        float* const S0 = f.cd[0] + o;
+        float* const S1 = f.cd[1] + o;
         if (e == 0) { *S0 = __builtin_fmaf(f.coeff, vy.x, mv.x0); *S1 = __builtin_fmaf(f.coeff, vz.x, mv.x1); }
         if (e == 1) { *S0 = __builtin_fmaf(f.coeff, vy.y, mv.x0); *S1 = __builtin_fmaf(f.coeff, vz.y, mv.x1); }
         if (e == 2) { *S0 = __builtin_fmaf(f.coeff, vy.z, mv.x0); *S1 = __builtin_fmaf(f.coeff, vz.z, mv.x1); }
@@ -319,8 +313,8 @@ __global__ __launch_bounds__(FDTD_BLOCK, (PML || P2P) ? FDTD_E_MINBLOCKS - 1 : F
   __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];   // (b, c, 1/kappa) of the x-layer cells, by psi slot
   double* const s_red = reinterpret_cast<double*>(s_psi);
   __shared__ SrcStage s_src;
-  if (FUSE && extra && blockIdx.x == gridDim.x - 1) {   // probe block: H-probes of the step just finished
-    probe_block(p, FDTD_KIND_I, step - 1, s_red);
+  if (FUSE && extra && blockIdx.x >= gridDim.x - (unsigned)extra) {   // probe blocks (one per probe): H-probes of the step just finished
+    probe_block(p, FDTD_KIND_I, step - 1, s_red, (int)(blockIdx.x - (gridDim.x - (unsigned)extra)));
     return;
   }
   int strip, kk, pb, k;
@@ -335,14 +329,14 @@ __global__ __launch_bounds__(FDTD_BLOCK, (PML || P2P) ? FDTD_E_MINBLOCKS - 1 : F
 
 // update_E of a single slab with Mur faces, sources fused: the "post" pass rides along (one launch less per timestep).
 template <int COEF, bool PML>
-__global__ __launch_bounds__(FDTD_BLOCK, 4) void k_update_E_mur(const DevParams p, const int k_begin, const FastDiv fd_ps,
+__global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E_mur(const DevParams p, const int k_begin, const FastDiv fd_ps,
                                                                                 const long long step, const int extra, const MurDev m) {
   extern __shared__ float2 s_lut[];
   __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : 3 * FDTD_BLOCK];
   __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
   __shared__ SrcStage s_src;
-  if (extra && blockIdx.x == gridDim.x - 1) {   // probe block: H-probes of the step just finished
-    probe_block(p, FDTD_KIND_I, step - 1, reinterpret_cast<double*>(s_psi));
+  if (extra && blockIdx.x >= gridDim.x - (unsigned)extra) {   // probe blocks (one per probe): H-probes of the step just finished
+    probe_block(p, FDTD_KIND_I, step - 1, reinterpret_cast<double*>(s_psi), (int)(blockIdx.x - (gridDim.x - (unsigned)extra)));
     return;
   }
   int strip, kk, pb;
@@ -666,7 +660,7 @@ __global__ __launch_bounds__(FDTD_BLOCK, (RAW || PML) ? FDTD_H_MINBLOCKS - 1 : F
   if (extra && blockIdx.x >= gridDim.x - (unsigned)extra) {   // the extra blocks at the end of the grid:
     const unsigned e = blockIdx.x - (gridDim.x - (unsigned)extra);
     if (e < (unsigned)p.mur_nb) mur_pre_block(p, e);          // Mur pre pass of the next step (V is final, H not read); MUR: the main blocks do it
-    else probe_block(p, FDTD_KIND_V, step, s_red);            // last one: V-probes of this step
+    else probe_block(p, FDTD_KIND_V, step, s_red, (int)e - p.mur_nb);   // the last ones, one per probe: V-probes of this step
     return;
   }
   int strip, kk, pb, k;
@@ -1290,7 +1284,7 @@ static void launch_E2(fdtd_ctx* c, int k_begin, int nkr, long long step, bool fu
 void launch_update_E(fdtd_ctx* c, int k_begin, int k_end, long long step, bool fused, bool probe_block, hipStream_t s) {
   const int nkr = k_end - k_begin;
   if (nkr <= 0) return;
-  const int extra = (fused && probe_block) ? 1 : 0;
+  const int extra = (fused && probe_block) ? c->nprobe : 0;   // one block per probe (those of the other kind leave at once)
   const int coef = c->raw_op ? 0 : (c->packed_op ? 2 : 1);
   if (c->have_cpml) {
     if (coef == 0) launch_E2<0, true>(c, k_begin, nkr, step, fused, extra, s);
@@ -1330,7 +1324,7 @@ void launch_update_H(fdtd_ctx* c, int k_begin, int k_end, long long step, bool p
   c->p.mur_nb = (mur_pre && probe_block && c->any_mur && c->d_mur) ? 12 * c->p.mur_nbx : 0;
   c->p.mur_direct = (c->mur_direct && c->p.mur_nb > 0) ? 1 : 0;   // (phase_E skipped the apply launch on the same condition)
   if (c->p.mur_direct) c->p.mur_nb = 0;                           // no apply pass: the main blocks store boundary voltages and st themselves
-  const int extra = (probe_block ? 1 : 0) + c->p.mur_nb;
+  const int extra = (probe_block ? c->nprobe : 0) + c->p.mur_nb;
   if (c->raw_op) {
     if (c->have_cpml) launch_H2<true, true>(c, k_begin, nkr, step, extra, s);
     else launch_H2<true, false>(c, k_begin, nkr, step, extra, s);
