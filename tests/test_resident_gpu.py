@@ -145,7 +145,7 @@ def test_resident_equals_two_launch_schedule_in_chunks(hip_lib):
             e.run(n)
         out.append((s, e))
     (sr, er), (sd, ed) = out
-    assert er.schedule_info()["resident"] and not ed.schedule_info()["resident"] and ed.schedule_info()["launches_per_timestep"] == 3
+    assert er.schedule_info()["resident"] and not ed.schedule_info()["resident"] and ed.schedule_info()["launches_per_timestep"] == 2
     assert er.step == ed.step == 300
     assert np.array_equal(er.fields(), ed.fields())
     for (ur, ir), (ud, id_) in zip(sr.port_series(), sd.port_series()):
@@ -162,9 +162,9 @@ def test_auto_takes_the_resident_schedule_for_mur_scenes_only(hip_lib):
     e = patch_sim(300, 300, 60, boundary="MUR", nr_ts=10, nf2ff=False).build(hip_lib, flags=capi.FLAG_KERNEL_RESIDENT)
     with pytest.raises(capi.FdtdError, match="resident schedule"):
         e.run(2)
-    # too many tiles for the chip: AUTO falls back to three launches per timestep
+    # too many tiles for the chip: AUTO falls back to two launches per timestep (update_E + post, update_H + pre: no apply pass)
     big = patch_sim(300, 300, 60, boundary="MUR", nr_ts=10, nf2ff=False).build(hip_lib)
-    assert not big.schedule_info()["resident"] and big.schedule_info()["launches_per_timestep"] == 3
+    assert not big.schedule_info()["resident"] and big.schedule_info()["launches_per_timestep"] == 2
 
 
 def test_resident_halo_timeout_heals_itself(hip_lib, monkeypatch):

@@ -93,3 +93,53 @@ def test_numerical_dispersion_relation_on_the_gpu(hip_lib, flag):
     import test_oracle_invariants_cpu as inv
     capi = pkg("_capi")
     inv._dispersion(hip_lib, False, flags={"AUTO": 0, "DIRECT": capi.FLAG_KERNEL_DIRECT}[flag])
+
+
+@pytest.mark.parametrize("shape", [(48, 44, 30), (61, 37, 23), (132, 70, 26)])
+@pytest.mark.parametrize("kinds", [["MUR"] * 6, ["MUR", "PEC", "CPML", "MUR", "MUR", "CPML"]])
+def test_mur_without_an_apply_pass_equals_the_apply_pass_and_the_oracle(hip_lib, oracle_lib, monkeypatch, shape, kinds):
+    """Mur faces beyond the resident schedule: update_H takes the boundary voltages from the candidates of the post pass (stored behind the
+    voltage arrays) and runs the pre pass itself — two launches per timestep.  Same fields, bit for bit, as with the apply pass as a launch
+    of its own (FDTD_MUR_APPLY_PASS=1: three launches) and as the oracle; port series and recorded NF2FF faces alike."""
+    monkeypatch.setenv("FDTD_RESIDENT", "0")
+    out = []
+    for lib, env in ((hip_lib, None), (hip_lib, "1"), (oracle_lib, None)):
+        if env:
+            monkeypatch.setenv("FDTD_MUR_APPLY_PASS", env)
+        s = patch_sim(*shape, boundary=kinds, cpml_cells=5, nr_ts=240, nf2ff_mode="record")
+        e = s.build(lib)
+        if env:
+            monkeypatch.delenv("FDTD_MUR_APPLY_PASS")
+        seeded_fields(e, 11)
+        for n in (1, 2, 77, 160):
+            e.run(n)
+        out.append((s, e))
+    (s2, e2), (s3, e3), (so, eo) = out
+    assert e2.schedule_info()["launches_per_timestep"] == 2 and e3.schedule_info()["launches_per_timestep"] == 3
+    f2, f3, fo = e2.fields(), e3.fields(), eo.fields()
+    assert np.abs(fo).max() > 0 and np.array_equal(f2, fo) and np.array_equal(f3, fo)
+    for sa in (s2, s3):
+        for (ua, ia), (ub, ib) in zip(sa.port_series(), so.port_series()):
+            assert np.allclose(ua, ub, rtol=0, atol=1e-12 * np.abs(ub).max()) and np.allclose(ia, ib, rtol=0, atol=1e-12 * np.abs(ib).max())
+        for a, b in zip(sa.nf2ff_boxes(), so.nf2ff_boxes()):
+            assert np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-9 * np.abs(b).max()
+
+
+def test_mur_probe_on_a_face_keeps_the_apply_pass(hip_lib, oracle_lib, monkeypatch):
+    """Without the apply pass the boundary voltages in memory are the E update's own while update_H runs; a voltage probe that holds a node of
+    a Mur face would sample them — such a scene keeps three launches per timestep (api.hip: mur_direct_possible), and equals the oracle."""
+    monkeypatch.setenv("FDTD_RESIDENT", "0")
+    out = []
+    for lib in (hip_lib, oracle_lib):
+        s = patch_sim(48, 44, 30, boundary="MUR", nr_ts=150, nf2ff=False)
+        e = s.build(lib)
+        nx, ny = 48, 44
+        idx = np.array([(7 * ny + 9) * nx + 0, (7 * ny + 9) * nx + 1], dtype=np.int64)      # nodes (0, 9, 7) and (1, 9, 7): the first on the lower x face
+        pid = e.add_probe(0, idx, np.array([1, 1], dtype=np.int8), np.array([1.0, 1.0], dtype=np.float32))
+        seeded_fields(e, 5)
+        e.run(150)
+        out.append((e, e.get_probe(pid)))
+    (eh, ph), (eo, po) = out
+    assert eh.schedule_info()["launches_per_timestep"] == 3
+    assert np.array_equal(eh.fields(), eo.fields())
+    assert np.abs(po).max() > 0 and np.abs(ph - po).max() <= 1e-12 * np.abs(po).max()
