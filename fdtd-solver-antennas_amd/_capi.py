@@ -410,8 +410,7 @@ class Engine:
         """Launches per timestep, lag, tiling and halo transport of this context (fdtd_schedule_info)."""
         a = np.zeros(8, np.int32)
         self._ck(self.lib.fdtd_schedule_info(self._ctx, _ptr(a)), "schedule_info")
-        return {"launches_per_timestep": int(a[0]), "lag_planes": int(a[1]) if a[1] >= 0 else -1, "resident": bool(a[1] < 0),
-                "hops_per_timestep": {-1: 2, -2: 1}.get(int(a[1]), 0), "rows_per_strip": int(a[2]),
+        return {"launches_per_timestep": int(a[0]), "lag_planes": int(a[1]), "resident": bool(a[1] == -1), "rows_per_strip": int(a[2]),
                 "blocks_per_sweep": int(a[3]),
                 "transport": ("none", "p2p", "rccl", "linked", "external")[int(a[4])] if 0 <= a[4] <= 4 else None,
                 "xcd_shares_weighted": bool(a[5]), "xcd_adaptations": int(a[6]), "timesteps_per_launch_max": int(a[7])}

@@ -194,7 +194,6 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   if (const char* v = getenv("FDTD_WF_LAG")) c->wf_lag = std::max(0, std::min(4096, atoi(v)));
   if (const char* v = getenv("FDTD_RCCL_INLINE")) c->rccl_inline_mode = atoi(v) ? 1 : 0;  // RCCL halos in stream order on the compute stream (1) / overlapped on the communication stream (0)
   if (const char* v = getenv("FDTD_RESIDENT")) c->res_mode = atoi(v) ? 1 : 0;          // 1: the resident schedule whenever it is possible, 0: never
-  if (const char* v = getenv("FDTD_RES_ONEHOP")) c->res_onehop = atoi(v) != 0;
   if (const char* v = getenv("FDTD_RES_CHUNK")) c->res_chunk = std::max(1, std::min(4096, atoi(v)));
   if (const char* v = getenv("FDTD_WF_MULTI")) c->wf_multi = std::max(1, std::min(4096, atoi(v)));   // timesteps per launch at most (1: one launch per timestep)
   if (const char* v = getenv("FDTD_OCC_H")) c->occ_h = std::max(0, std::min(16, atoi(v)));
@@ -1625,7 +1624,7 @@ int fdtd_schedule_info(fdtd_ctx* c, int32_t info[8]) {
   const bool res = steppable && resident_active(c);
   const bool wf = steppable && !res && wavefront_active(c);
   info[0] = !steppable ? 0 : res ? 1 : wf ? 1 : !c->any_mur ? 2 : mur_direct_possible(c, multi, sources_fusable(c)) ? 2 : (sources_fusable(c) && !multi && c->mur_fuse_post) ? 3 : 5;
-  info[1] = res ? (c->res.onehop ? -2 : -1) : wf ? wf_lag_for(c) : 0;   // (resident_active has just decided which resident kernel)
+  info[1] = res ? -1 : wf ? wf_lag_for(c) : 0;
   info[2] = c->p.tys;
   info[3] = c->d.nk * c->p.nstrips * c->p.nbs;
   info[4] = !multi ? 0 : c->p.p2p ? 1 : c->comm ? 2 : (c->link_lo || c->link_hi) ? 3 : 4;

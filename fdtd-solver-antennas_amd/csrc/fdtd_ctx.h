@@ -150,8 +150,6 @@ struct ResHost {
   int* err = nullptr;
   int nsrc_seen = -1, nprobe_seen = -1;
   int capacity = -1, capacity_variant = -1;   // workgroups of k_resident the chip holds at once (occupancy query), for which kernel variant
-  int capacity1 = 0;                          // ... of k_resident1 (one hop per timestep)
-  bool onehop = false;                        // this context steps with k_resident1 (res_possible decides)
 };
 
 struct fdtd_ctx {
@@ -179,7 +177,6 @@ struct fdtd_ctx {
   int* wf_prbV_sp = nullptr; unsigned* wf_prb_done = nullptr;
   int res_mode = -1;             // grid resident in registers (k_resident): -1 auto, 0 never, 1 whenever possible; $FDTD_RESIDENT
   int res_chunk = 256;           // timesteps per resident launch at most; $FDTD_RES_CHUNK
-  bool res_onehop = true;        // allow k_resident1; $FDTD_RES_ONEHOP=0 clears
   ResHost res;
   int wf_multi = 64;             // timesteps per launch at most (cache-resident single slabs without Mur faces); 1 = one launch per timestep; $FDTD_WF_MULTI
   bool wf_prb_dirty = true;      // probe tables of the wavefront launch need rebuilding (a probe was added)

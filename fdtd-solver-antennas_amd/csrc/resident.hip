@@ -25,6 +25,10 @@
 // once (they wait for each other): the launcher checks the grid against the occupancy query, every wait is bounded
 // (error word -> FDTD_E_DEVICE, simulation.Simulation.run repeats the run under the two-launch schedule).
 //
+// ONE exchange per timestep instead of two (ghost currents updated redundantly by the neighbour tile, so that E needs nothing from outside)
+// was built as well: bit-exact, and slower — 4.8 against 4.5 us on the default scene, the one hop of 2.5x the bytes costs 2.2-2.9 us and the
+// redundant work sits on the critical cycle (profiles/r04/resident_one_hop_negative.txt; the kernel is in the history).
+//
 // Float32 operation order is that of body_E / body_H (kernels.hip) and of oracle/fdtd_oracle.c: compared bit for bit.
 #include <hip/hip_ext.h>
 #include <algorithm>
@@ -473,360 +477,6 @@ __global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident(const DevParams p, c
   }
 }
 
-// ---- ONE hop per timestep (k_resident1) ------------------------------------------------------------------------------------------
-// k_resident above pays two dependent hops per timestep: a tile's H needs the voltages its neighbours' E has just produced, and its next E
-// the currents their H has just produced — the bottom plane of a tile and the top plane of the tile below play ping-pong, 2 x 1.7 us of a
-// 4.5 us timestep (profiles/r04/resident_phase_trace.txt).  Here a tile ALSO updates the currents of the plane below its bottom plane and of
-// the row in front of its first row (ghost cells: Ix, Iy of that plane, Iz, Ix of that row — exactly what its own E update reads across the
-// tile border), redundantly with their owner and bit for bit the same: H carries no sources, no Mur and (without CPML) no state but I itself.
-// Then E needs nothing from outside the tile, the I halos are gone, and the only exchange of a timestep is V after E:
-//   down / backwards (as before): Vx, Vy of the bottom plane, Vz, Vx of the first row — the k + 1 / j + 1 neighbours of the tile below / before;
-//   up / forwards (new): Vx, Vy, Vz of the top plane and of the last row — what the tile above / behind needs to update its ghost cells;
-//   the two diagonal rows a ghost cell's stencil reaches (Vz of row j1 + 1 in the ghost plane, Vy of plane k1 + 1 in the ghost row) are rows the
-//   diagonal tiles publish anyway (first row / bottom plane).
-// Every halo a tile pulls goes through ONE list of (granule offset, LDS staging index) items spread evenly over its 256 threads (at most 4 each: all
-// loads of a round in flight together, whoever needs the value afterwards), then one more barrier.  Without CPML and with class-byte operators only;
-// tiles of two planes (rows of at most 256 cells).  Everything else — sources, Mur inside the tile, probe cells, the NF2FF record — as k_resident.
-constexpr int RES1_STAGE = 1664;      // float4 entries of the staging area: 2 RP + 2 ZP + 3 (R + 1) P4 + 3 (ZT + 1) P4 with ZT RP <= 256, ZT <= 2, P4 <= 64
-constexpr int RES1_ITEMS = 4;         // pull items per thread at most (res1_possible)
-__device__ __forceinline__ unsigned gx1_slot(const unsigned blk, const unsigned kind, const unsigned comp) {
-  return (((blk * 4u + kind) * 3u + comp) * 256u) * 8u;   // float offset of a (kind, comp) slot inside one parity half
-}
-enum { G1_KDOWN = 0, G1_JDOWN = 1, G1_KUP = 2, G1_JUP = 3 };
-
-template <int COEF, bool MUR>
-__global__ __launch_bounds__(FDTD_BLOCK, 2) void k_resident1(const DevParams p, const ResDev r) {
-  static_assert(COEF != 0, "class-byte operators only (ii = 1)");
-  __shared__ float4 sV[3][FDTD_BLOCK], sI[3][FDTD_BLOCK];
-  __shared__ float4 sO[MUR ? 3 : 1][MUR ? FDTD_BLOCK : 1];
-  __shared__ float4 sG[RES1_STAGE];
-  __shared__ int s_sthr[RES_MAX_SRC], s_sdel[RES_MAX_SRC];
-  __shared__ float s_samp[RES_MAX_SRC], s_sval[RES_MAX_SRC];
-  __shared__ signed char s_ssel[RES_MAX_SRC];
-  __shared__ int s_pthr[RES_MAX_PRB], s_pslot[RES_MAX_PRB];
-  __shared__ signed char s_psel[RES_MAX_PRB];
-
-  const unsigned b = blockIdx.x, nblocks = gridDim.x;
-#ifdef FDTD_RES_TRACE
-  const unsigned long long tr_begin = wall_clock64();
-  unsigned long long tr_ew = 0, tr_ec = 0, tr_hw = 0, tr_hc = 0, tr_setup = 0;
-#endif
-  const int zt = (int)(b / (unsigned)r.nstrips), strip = (int)(b - (unsigned)zt * (unsigned)r.nstrips);
-  const int k0 = r.kt[zt], ZT = r.kt[zt + 1] - k0, j0 = r.jt[strip], R = r.jt[strip + 1] - j0;
-  const int P4 = p.P4, RP = R * P4, ZP = ZT * P4, nth = ZT * RP;
-  const int t = (int)threadIdx.x;
-  const bool valid = t < nth;
-  const int tt = valid ? t : 0;
-  const int kk = tt / RP, rem = tt - kk * RP, rr = rem / P4, g = rem - rr * P4;
-  const int k = k0 + kk, j = j0 + rr, i0 = 4 * g;
-  const int off = k * p.plane + j * p.P + i0;
-  const DevRsrc rs = dev_buf(r.gx);
-  const bool hasDn = zt > 0, hasUp = zt < r.nzt - 1, hasBk = strip > 0, hasFw = strip < r.nstrips - 1;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  // ---- state: fields and coefficients of this thread's four cells ----------------------------------------------------------------
-  float4 vx = ld4(p.V[0] + off), vy = ld4(p.V[1] + off), vz = ld4(p.V[2] + off);
-  float4 ix = ld4(p.I[0] + off), iy = ld4(p.I[1] + off), iz = ld4(p.I[2] + off);
-  float4 ea[3], eb[3], hb[3];
-  auto h_coef = [&](const int comp, const int kq, const int jq) {   // iv of the four cells i0.. of row jq in plane kq
-    const float4 hx = ld4(p.hmet[comp][0] + i0);
-    const float mh = p.hmet[comp][1][jq] * p.hmet[comp][2][kq];
-    return make_float4(hx.x * mh, hx.y * mh, hx.z * mh, hx.w * mh);
-  };
-  {
-    uchar4 cc = make_uchar4(0, 0, 0, 0);
-    if (COEF == 2) cc = *reinterpret_cast<const uchar4*>(p.ecls + off);
-#pragma unroll
-    for (int comp = 0; comp < 3; ++comp) {
-      const float4 ex = ld4(p.emet[comp][0] + i0);
-      const float m = p.emet[comp][1][j] * p.emet[comp][2][k];
-      float2 l0, l1, l2, l3;
-      if (COEF == 1) {
-        const uchar4 c1 = *reinterpret_cast<const uchar4*>(p.ecls + comp * p.nloc + off);
-        l0 = p.lut[c1.x]; l1 = p.lut[c1.y]; l2 = p.lut[c1.z]; l3 = p.lut[c1.w];
-      } else {
-        l0 = p.lut[3 * cc.x + comp]; l1 = p.lut[3 * cc.y + comp]; l2 = p.lut[3 * cc.z + comp]; l3 = p.lut[3 * cc.w + comp];
-      }
-      ea[comp] = make_float4(l0.x, l1.x, l2.x, l3.x);
-      eb[comp] = make_float4(l0.y * (ex.x * m), l1.y * (ex.y * m), l2.y * (ex.z * m), l3.y * (ex.w * m));
-      hb[comp] = h_coef(comp, k, j);
-    }
-  }
-  // ghost cells: the plane below (threads of the tile's bottom plane), the row in front (threads of its first row)
-  const bool ghostK = valid && kk == 0 && hasDn, ghostJ = valid && rr == 0 && hasBk;
-  float4 gkx = zero4, gky = zero4, gjz = zero4, gjx = zero4;          // Ix, Iy at (k0 - 1, j); Iz, Ix at (k, j0 - 1)
-  float4 hgkx = zero4, hgky = zero4, hgjz = zero4, hgjx = zero4;      // their iv
-  if (ghostK) {
-    gkx = ld4(p.I[0] + off - p.plane); gky = ld4(p.I[1] + off - p.plane);
-    hgkx = h_coef(0, k - 1, j); hgky = h_coef(1, k - 1, j);
-  }
-  if (ghostJ) {
-    gjz = ld4(p.I[2] + off - p.P); gjx = ld4(p.I[0] + off - p.P);
-    hgjz = h_coef(2, k, j - 1); hgjx = h_coef(0, k, j - 1);
-  }
-  // soft sources and probe cells of this tile -> LDS (as k_resident)
-  const int2 srng = r.src_rng[b];
-  const int nsrc_t = min(srng.y - srng.x, RES_MAX_SRC);
-  if (t < nsrc_t) {
-    const int e = r.src_ids[srng.x + t];
-    const int so = p.src_off[e];
-    const int sk = so / p.plane, s2 = so - sk * p.plane, sj = s2 / p.P, si = s2 - sj * p.P;
-    s_sthr[t] = ((sk - k0) * R + (sj - j0)) * P4 + (si >> 2);
-    s_ssel[t] = (signed char)(p.src_comp[e] * 4 + (si & 3));
-    s_samp[t] = p.src_amp[e];
-    s_sdel[t] = p.src_delay[e];
-  }
-  const int2 prng = r.prb_rng[b];
-  const int nprb_t = min(prng.y - prng.x, RES_MAX_PRB);
-  int npv = 0;
-  for (int q = t; q < nprb_t; q += FDTD_BLOCK) {
-    const int4 pc = r.prb_cells[prng.x + q];
-    s_pthr[q] = pc.x; s_psel[q] = (signed char)pc.y; s_pslot[q] = pc.z;
-  }
-  for (int q = 0; q < nprb_t; ++q) npv += r.prb_cells[prng.x + q].w == FDTD_KIND_V ? 1 : 0;
-  const bool rec_on = r.nbox > 0;
-
-  // ---- the halo list of this tile: staging layout, items of this thread ------------------------------------------------------------
-  const int GKS = (R + 1) * P4, GJS = (ZT + 1) * P4;                  // one component of the ghost plane (+ the diagonal row) / ghost row (+ the diagonal plane)
-  const int oKP = 0, oJP = oKP + 2 * RP, oGK = oJP + 2 * ZP, oGJ = oGK + 3 * GKS;
-  for (int q = t; q < oGJ + 3 * GJS; q += FDTD_BLOCK) sG[q] = zero4;   // (what no neighbour fills stays zero: the grid's outer faces)
-  unsigned it_src[RES1_ITEMS];
-  int it_dst[RES1_ITEMS];
-  {
-    const int ZTdn = hasDn ? k0 - r.kt[zt - 1] : 1, Rbk = hasBk ? j0 - r.jt[strip - 1] : 1;
-    const int n0 = hasUp ? 2 * RP : 0, n1 = hasFw ? 2 * ZP : 0, n2 = hasDn ? 3 * RP : 0, n3 = hasBk ? 3 * ZP : 0;
-    const int n4 = (hasDn && hasFw) ? P4 : 0, n5 = (hasBk && hasUp) ? P4 : 0;
-#pragma unroll
-    for (int qq = 0; qq < RES1_ITEMS; ++qq) {
-      int q = t + qq * FDTD_BLOCK;
-      unsigned src = 0u;
-      int dst = -1;
-      if (q < n0) { const int cq = q / RP, iq = q - cq * RP; src = gx1_slot(b + (unsigned)r.nstrips, G1_KDOWN, (unsigned)cq) + 8u * (unsigned)iq; dst = oKP + cq * RP + iq; }
-      else if ((q -= n0) < n1) { const int cq = q / ZP, iq = q - cq * ZP; src = gx1_slot(b + 1u, G1_JDOWN, (unsigned)cq) + 8u * (unsigned)iq; dst = oJP + cq * ZP + iq; }
-      else if ((q -= n1) < n2) { const int cq = q / RP, iq = q - cq * RP; src = gx1_slot(b - (unsigned)r.nstrips, G1_KUP, (unsigned)cq) + 8u * (unsigned)iq; dst = oGK + cq * GKS + iq; }
-      else if ((q -= n2) < n3) { const int cq = q / ZP, iq = q - cq * ZP; src = gx1_slot(b - 1u, G1_JUP, (unsigned)cq) + 8u * (unsigned)iq; dst = oGJ + cq * GJS + iq; }
-      else if ((q -= n3) < n4) { src = gx1_slot(b - (unsigned)r.nstrips + 1u, G1_JDOWN, 0u) + 8u * (unsigned)((ZTdn - 1) * P4 + q); dst = oGK + 2 * GKS + R * P4 + q; }   // Vz, row j1 + 1 of the ghost plane
-      else if ((q -= n4) < n5) { src = gx1_slot(b + (unsigned)r.nstrips - 1u, G1_KDOWN, 1u) + 8u * (unsigned)((Rbk - 1) * P4 + q); dst = oGJ + GJS + ZT * P4 + q; }        // Vy, plane k1 + 1 of the ghost row
-      it_src[qq] = src; it_dst[qq] = dst;
-    }
-  }
-  const unsigned half = nblocks * 4u * 3u * 256u * 8u;   // floats of one parity half of the exchange buffer
-  const unsigned idxK = (unsigned)(rr * P4 + g), idxJ = (unsigned)(kk * P4 + g);
-  const bool pushKD = valid && kk == 0 && hasDn, pushJD = valid && rr == 0 && hasBk;
-  const bool pushKU = valid && kk == ZT - 1 && hasUp, pushJU = valid && rr == R - 1 && hasFw;
-
-  sI[0][t] = ix; sI[1][t] = iy; sI[2][t] = iz;
-#ifdef FDTD_RES_TRACE
-  tr_setup = wall_clock64() - tr_begin;
-#endif
-  for (int n = 0; n < r.nsteps; ++n) {
-    RES_T(tr0);
-    const long long step = r.step0 + n;
-    const unsigned par = (unsigned)n & 1u;
-    const unsigned tagV = r.tag0 + (unsigned)n + 1u;
-
-    // ================= E half-step: nothing from outside the tile ================================================================
-    if (t < nsrc_t) {
-      const long long ts = step - s_sdel[t];
-      s_sval[t] = (ts >= 0 && ts < p.nsig) ? s_samp[t] * p.sig[ts] : 0.f;
-    }
-    lds_barrier();   // every thread's I of the previous half-step is in sI (and nobody reads the staging area any more)
-#ifdef FDTD_RES_TRACE
-    tr_ew += wall_clock64() - tr0;   // (here: the barrier at the top of the timestep)
-#endif
-    {
-      float4 iy_km = gky, ix_km = gkx, iz_jm = gjz, ix_jm = gjx;   // (zero on the grid's outer faces)
-      float iz_im = 0.f, iy_im = 0.f;
-      if (valid) {
-        if (kk > 0) { iy_km = sI[1][t - RP]; ix_km = sI[0][t - RP]; }
-        if (rr > 0) { iz_jm = sI[2][t - P4]; ix_jm = sI[0][t - P4]; }
-        if (t > 0) { iz_im = sI[2][t - 1].w; iy_im = sI[1][t - 1].w; }
-      }
-      float4 dx1 = sub4(iz, iz_jm), dx2 = sub4(iy, iy_km);
-      float4 dy1 = sub4(ix, ix_km);
-      float4 dy2 = make_float4(iz.x - iz_im, iz.y - iz.x, iz.z - iz.y, iz.w - iz.z);
-      float4 dz1 = make_float4(iy.x - iy_im, iy.y - iy.x, iy.z - iy.y, iy.w - iy.z);
-      float4 dz2 = sub4(ix, ix_jm);
-      if (MUR) { sO[0][t] = vx; sO[1][t] = vy; sO[2][t] = vz; }
-      vx = upd4(ea[0], vx, eb[0], dx1, dx2);
-      vy = upd4(ea[1], vy, eb[1], dy1, dy2);
-      vz = upd4(ea[2], vz, eb[2], dz1, dz2);
-    }
-    for (int q = 0; q < nsrc_t; ++q) {
-      if (s_sthr[q] != t) continue;
-      const float a = s_sval[q];
-      if (a == 0.f) continue;
-      const int sel = s_ssel[q];
-      const int se = sel & 3;
-      if ((sel >> 2) == 0) vx = f4_with(vx, se, f4_elem(vx, se) + a);
-      else if ((sel >> 2) == 1) vy = f4_with(vy, se, f4_elem(vy, se) + a);
-      else vz = f4_with(vz, se, f4_elem(vz, se) + a);
-    }
-    if (MUR) {
-      sV[0][t] = vx; sV[1][t] = vy; sV[2][t] = vz;
-      lds_barrier();
-      if (valid) {
-        if (r.mur_on[0] && g == 0) {
-          const float co = r.mur_c[0];
-          const float4 ny_ = sV[1][t], oy = sO[1][t], nz_ = sV[2][t], oz = sO[2][t];
-          vy.x = mur_cand(co, ny_.y, oy.x, oy.y);
-          vz.x = mur_cand(co, nz_.y, oz.x, oz.y);
-        }
-        if (r.mur_on[1] && g == ((p.nx - 1) >> 2)) {
-          const float co = r.mur_c[1];
-          const int e = (p.nx - 1) & 3;
-          const float4 ny_ = sV[1][t], oy = sO[1][t], nz_ = sV[2][t], oz = sO[2][t];
-          float iny, ioy, inz, ioz;
-          if (e > 0) { iny = f4_elem(ny_, e - 1); ioy = f4_elem(oy, e - 1); inz = f4_elem(nz_, e - 1); ioz = f4_elem(oz, e - 1); }
-          else { iny = sV[1][t - 1].w; ioy = sO[1][t - 1].w; inz = sV[2][t - 1].w; ioz = sO[2][t - 1].w; }
-          vy = f4_with(vy, e, mur_cand(co, iny, f4_elem(oy, e), ioy));
-          vz = f4_with(vz, e, mur_cand(co, inz, f4_elem(oz, e), ioz));
-        }
-        if (r.mur_on[2] && j == 0) {
-          const float co = r.mur_c[2];
-          vz = mur_cand4(co, sV[2][t + P4], sO[2][t], sO[2][t + P4]);
-          vx = mur_cand4(co, sV[0][t + P4], sO[0][t], sO[0][t + P4]);
-        }
-        if (r.mur_on[3] && j == p.ny - 1) {
-          const float co = r.mur_c[3];
-          vz = mur_cand4(co, sV[2][t - P4], sO[2][t], sO[2][t - P4]);
-          vx = mur_cand4(co, sV[0][t - P4], sO[0][t], sO[0][t - P4]);
-        }
-        if (r.mur_on[4] && k == 0) {
-          const float co = r.mur_c[4];
-          vx = mur_cand4(co, sV[0][t + RP], sO[0][t], sO[0][t + RP]);
-          vy = mur_cand4(co, sV[1][t + RP], sO[1][t], sO[1][t + RP]);
-        }
-        if (r.mur_on[5] && k == p.nk - 1) {
-          const float co = r.mur_c[5];
-          vx = mur_cand4(co, sV[0][t - RP], sO[0][t], sO[0][t - RP]);
-          vy = mur_cand4(co, sV[1][t - RP], sO[1][t], sO[1][t - RP]);
-        }
-      }
-      lds_barrier();
-    }
-    sV[0][t] = vx; sV[1][t] = vy; sV[2][t] = vz;
-    {   // the one exchange of the timestep
-      float* const gxp = r.gx + (size_t)par * half;
-      if (pushKD) { gx_push(gxp, gx1_slot(b, G1_KDOWN, 0), idxK, tagV, vx); gx_push(gxp, gx1_slot(b, G1_KDOWN, 1), idxK, tagV, vy); }
-      if (pushJD) { gx_push(gxp, gx1_slot(b, G1_JDOWN, 0), idxJ, tagV, vz); gx_push(gxp, gx1_slot(b, G1_JDOWN, 1), idxJ, tagV, vx); }
-      if (pushKU) { gx_push(gxp, gx1_slot(b, G1_KUP, 0), idxK, tagV, vx); gx_push(gxp, gx1_slot(b, G1_KUP, 1), idxK, tagV, vy); gx_push(gxp, gx1_slot(b, G1_KUP, 2), idxK, tagV, vz); }
-      if (pushJU) { gx_push(gxp, gx1_slot(b, G1_JUP, 0), idxJ, tagV, vx); gx_push(gxp, gx1_slot(b, G1_JUP, 1), idxJ, tagV, vy); gx_push(gxp, gx1_slot(b, G1_JUP, 2), idxJ, tagV, vz); }
-    }
-    for (int q = 0; q < npv; ++q) {
-      if (s_pthr[q] != t) continue;
-      const int sel = s_psel[q], e = sel & 3;
-      r.stage[(size_t)n * r.nslots + s_pslot[q]] = (sel >> 2) == 0 ? f4_elem(vx, e) : ((sel >> 2) == 1 ? f4_elem(vy, e) : f4_elem(vz, e));
-    }
-    if (rec_on && step % r.every == 0 && step / r.every < r.nsamples && valid) res_record(r, FDTD_KIND_V, step / r.every, k, j, i0, vx, vy, vz);
-
-    // ================= the halos of this timestep -> staging area =================================================================
-    RES_T(tr2);
-#ifdef FDTD_RES_TRACE
-    tr_ec += tr2 - tr0;
-#endif
-    {
-      const unsigned tag = tagV + r.pull_bias, pofs = par * half;
-      bool pend[RES1_ITEMS];
-#pragma unroll
-      for (int qq = 0; qq < RES1_ITEMS; ++qq) pend[qq] = it_dst[qq] >= 0;
-      unsigned long long t0 = 0ull;
-      for (int round = 0;; ++round) {
-        v4u_dev a0[RES1_ITEMS], a1[RES1_ITEMS];
-#pragma unroll
-        for (int qq = 0; qq < RES1_ITEMS; ++qq) {
-          if (!pend[qq]) continue;
-          const unsigned o = (pofs + it_src[qq]) << 2;
-          a0[qq] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o, 0, 16);
-          a1[qq] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o + 16, 0, 16);
-        }
-        bool any = false;
-#pragma unroll
-        for (int qq = 0; qq < RES1_ITEMS; ++qq) {
-          if (!pend[qq]) continue;
-          if (a0[qq].y == tag && a0[qq].w == tag && a1[qq].y == tag && a1[qq].w == tag) {
-            sG[it_dst[qq]] = make_float4(__uint_as_float(a0[qq].x), __uint_as_float(a0[qq].z), __uint_as_float(a1[qq].x), __uint_as_float(a1[qq].z));
-            pend[qq] = false;
-          } else any = true;
-        }
-        if (__ballot(any) == 0ull) break;
-#if RES_POLL_SLEEP > 0
-        __builtin_amdgcn_s_sleep(RES_POLL_SLEEP);
-#endif
-        if ((round & 31) != 31) continue;
-        if (t0 == 0ull) t0 = wall_clock64();
-        if (__hip_atomic_load(r.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if ((unsigned long long)wall_clock64() - t0 > r.limit) { __hip_atomic_store(r.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      }
-    }
-    lds_barrier();   // sV of this timestep and the staged halos are in LDS
-#ifdef FDTD_RES_TRACE
-    tr_hw += wall_clock64() - tr2;
-#endif
-
-    // ================= H half-step: own cells, then the ghost cells ================================================================
-    {
-      float4 vy_kp = zero4, vx_kp = zero4, vz_jp = zero4, vx_jp = zero4;
-      float vz_ip = 0.f, vy_ip = 0.f;
-      if (valid) {
-        if (kk < ZT - 1) { vy_kp = sV[1][t + RP]; vx_kp = sV[0][t + RP]; }
-        else { vx_kp = sG[oKP + (int)idxK]; vy_kp = sG[oKP + RP + (int)idxK]; }
-        if (rr < R - 1) { vz_jp = sV[2][t + P4]; vx_jp = sV[0][t + P4]; }
-        else { vz_jp = sG[oJP + (int)idxJ]; vx_jp = sG[oJP + ZP + (int)idxJ]; }
-        if (t + 1 < nth) { vz_ip = sV[2][t + 1].x; vy_ip = sV[1][t + 1].x; }
-      }
-      const float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);
-      const float4 dy1 = sub4(vx, vx_kp);
-      const float4 dy2 = make_float4(vz.x - vz.y, vz.y - vz.z, vz.z - vz.w, vz.w - vz_ip);
-      const float4 dz1 = make_float4(vy.x - vy.y, vy.y - vy.z, vy.z - vy.w, vy.w - vy_ip);
-      const float4 dz2 = sub4(vx, vx_jp);
-      ix = make_float4(ix.x + hb[0].x * (dx1.x - dx2.x), ix.y + hb[0].y * (dx1.y - dx2.y), ix.z + hb[0].z * (dx1.z - dx2.z), ix.w + hb[0].w * (dx1.w - dx2.w));
-      iy = make_float4(iy.x + hb[1].x * (dy1.x - dy2.x), iy.y + hb[1].y * (dy1.y - dy2.y), iy.z + hb[1].z * (dy1.z - dy2.z), iy.w + hb[1].w * (dy1.w - dy2.w));
-      iz = make_float4(iz.x + hb[2].x * (dz1.x - dz2.x), iz.y + hb[2].y * (dz1.y - dz2.y), iz.z + hb[2].z * (dz1.z - dz2.z), iz.w + hb[2].w * (dz1.w - dz2.w));
-    }
-    if (ghostK) {   // Ix, Iy of cell group (k0 - 1, j, g): its k + 1 neighbour is this thread's own cell group
-      const int q = (int)idxK;
-      const float4 wx = sG[oGK + q], wy = sG[oGK + GKS + q], wz = sG[oGK + 2 * GKS + q], wz_jp = sG[oGK + 2 * GKS + q + P4];
-      const float wz_ip = sG[oGK + 2 * GKS + q + 1].x;
-      const float4 dx1 = sub4(wz, wz_jp), dx2 = sub4(wy, vy);
-      const float4 dy1 = sub4(wx, vx);
-      const float4 dy2 = make_float4(wz.x - wz.y, wz.y - wz.z, wz.z - wz.w, wz.w - wz_ip);
-      gkx = make_float4(gkx.x + hgkx.x * (dx1.x - dx2.x), gkx.y + hgkx.y * (dx1.y - dx2.y), gkx.z + hgkx.z * (dx1.z - dx2.z), gkx.w + hgkx.w * (dx1.w - dx2.w));
-      gky = make_float4(gky.x + hgky.x * (dy1.x - dy2.x), gky.y + hgky.y * (dy1.y - dy2.y), gky.z + hgky.z * (dy1.z - dy2.z), gky.w + hgky.w * (dy1.w - dy2.w));
-    }
-    if (ghostJ) {   // Iz, Ix of cell group (k, j0 - 1, g): its j + 1 neighbour is this thread's own cell group
-      const int q = (int)idxJ;
-      const float4 wx = sG[oGJ + q], wy = sG[oGJ + GJS + q], wz = sG[oGJ + 2 * GJS + q], wy_kp = sG[oGJ + GJS + q + P4];
-      const float wy_ip = sG[oGJ + GJS + q + 1].x;
-      const float4 dz1 = make_float4(wy.x - wy.y, wy.y - wy.z, wy.z - wy.w, wy.w - wy_ip);
-      const float4 dz2 = sub4(wx, vx);
-      const float4 dx1 = sub4(wz, vz), dx2 = sub4(wy, wy_kp);
-      gjz = make_float4(gjz.x + hgjz.x * (dz1.x - dz2.x), gjz.y + hgjz.y * (dz1.y - dz2.y), gjz.z + hgjz.z * (dz1.z - dz2.z), gjz.w + hgjz.w * (dz1.w - dz2.w));
-      gjx = make_float4(gjx.x + hgjx.x * (dx1.x - dx2.x), gjx.y + hgjx.y * (dx1.y - dx2.y), gjx.z + hgjx.z * (dx1.z - dx2.z), gjx.w + hgjx.w * (dx1.w - dx2.w));
-    }
-    sI[0][t] = ix; sI[1][t] = iy; sI[2][t] = iz;
-    for (int q = npv; q < nprb_t; ++q) {
-      if (s_pthr[q] != t) continue;
-      const int sel = s_psel[q], e = sel & 3;
-      r.stage[(size_t)n * r.nslots + s_pslot[q]] = (sel >> 2) == 0 ? f4_elem(ix, e) : ((sel >> 2) == 1 ? f4_elem(iy, e) : f4_elem(iz, e));
-    }
-    if (rec_on && step % r.every == 0 && step / r.every < r.nsamples && valid) res_record(r, FDTD_KIND_I, step / r.every, k, j, i0, ix, iy, iz);
-#ifdef FDTD_RES_TRACE
-    tr_hc += wall_clock64() - tr2;
-#endif
-  }
-#ifdef FDTD_RES_TRACE
-  if (t == 0 && b < RES_TRACE_MAX) {
-    unsigned long long* q = g_res_trace + 8 * b;
-    q[0] = tr_ew; q[1] = tr_ec; q[2] = tr_hw; q[3] = tr_hc; q[4] = wall_clock64() - tr_begin; q[5] = tr_setup; q[6] = (unsigned long long)r.nsteps;
-  }
-#endif
-  if (valid) {
-    st4(p.V[0] + off, vx); st4(p.V[1] + off, vy); st4(p.V[2] + off, vz);
-    st4(p.I[0] + off, ix); st4(p.I[1] + off, iy); st4(p.I[2] + off, iz);
-  }
-}
-
 // series[step] = sum_e w[e] * cell[e] for probe blockIdx.x and timestep step0 + blockIdx.y of the launch, from the staged cell values:
 // probe_block's strided partial sums and tree (kernel_common.hpp) — identical sums to every other schedule
 __global__ __launch_bounds__(FDTD_BLOCK) void k_res_probes(const DevParams p, const float* __restrict__ stage, const int nslots,
@@ -864,10 +514,6 @@ const void* res_kernel_c(bool mur, bool pml) {
 const void* res_kernel_of(const fdtd_ctx* c) {
   const int coef = c->raw_op ? 0 : (c->packed_op ? 2 : 1);
   return coef == 0 ? res_kernel_c<0>(c->any_mur, c->have_cpml) : coef == 1 ? res_kernel_c<1>(c->any_mur, c->have_cpml) : res_kernel_c<2>(c->any_mur, c->have_cpml);
-}
-const void* res1_kernel_of(const fdtd_ctx* c) {   // the one-hop kernel of this context's operator form (class bytes only, no CPML)
-  if (c->packed_op) return c->any_mur ? reinterpret_cast<const void*>(&k_resident1<2, true>) : reinterpret_cast<const void*>(&k_resident1<2, false>);
-  return c->any_mur ? reinterpret_cast<const void*>(&k_resident1<1, true>) : reinterpret_cast<const void*>(&k_resident1<1, false>);
 }
 
 }  // namespace
@@ -929,33 +575,13 @@ bool res_possible(fdtd_ctx* c, const char** why) {
   const int variant = ((c->raw_op ? 0 : (c->packed_op ? 2 : 1)) * 2 + (c->any_mur ? 1 : 0)) * 2 + (c->have_cpml ? 1 : 0);
   if (c->res.capacity < 0 || c->res.capacity_variant != variant) {
     c->res.capacity_variant = variant;
-    int per_cu = 0, per_cu1 = 0, dev = c->d.device;
+    int per_cu = 0, dev = c->d.device;
     hipDeviceProp_t prop;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, res_kernel_of(c), FDTD_BLOCK, 0) != hipSuccess ||
-        hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); c->res.capacity = 0; c->res.capacity1 = 0; }
-    else {
-      c->res.capacity = per_cu * prop.multiProcessorCount;
-      c->res.capacity1 = 0;
-      if (!c->raw_op && !c->have_cpml && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu1, res1_kernel_of(c), FDTD_BLOCK, 0) == hipSuccess)
-        c->res.capacity1 = per_cu1 * prop.multiProcessorCount;
-      else (void)hipGetLastError();
-    }
+        hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); c->res.capacity = 0; }
+    else c->res.capacity = per_cu * prop.multiProcessorCount;
   }
-  // One hop per timestep (k_resident1) where it applies: class-byte operator, no CPML, tiles of two planes, a halo list of at most
-  // RES1_ITEMS items per thread and a staging area that fits; else the two-hop kernel.  $FDTD_RES_ONEHOP=0: never.
-  c->res.onehop = false;
-  if (c->res_onehop && !c->raw_op && !c->have_cpml && 4 * c->p.P4 <= FDTD_BLOCK && c->d.nk >= 4 && (long)nzt * nstrips <= c->res.capacity1) {
-    const int P4 = c->p.P4;
-    bool fits = true;
-    for (int s = 0; s < nstrips && fits; ++s) {
-      const int R = jt[s + 1] - jt[s], RP = R * P4, ZP = 2 * P4;
-      const int items = 2 * RP + 2 * ZP + 3 * RP + 3 * ZP + 2 * P4;
-      const int stage = 2 * RP + 2 * ZP + 3 * (R + 1) * P4 + 3 * 3 * P4;
-      if (items > RES1_ITEMS * FDTD_BLOCK || stage > RES1_STAGE) fits = false;
-    }
-    c->res.onehop = fits;
-  }
-  if (!c->res.onehop && (long)nzt * nstrips > c->res.capacity) { *why = "more tiles than the chip holds resident workgroups"; return false; }
+  if ((long)nzt * nstrips > c->res.capacity) { *why = "more tiles than the chip holds resident workgroups"; return false; }
   return true;
 }
 
@@ -1026,7 +652,7 @@ int res_prepare(fdtd_ctx* c, int max_chunk) {
     h.chunk_cap = max_chunk;
   }
   if (!h.gx) {   // granules start with tag 0 = never valid; tags only grow over the life of a context
-    const size_t bytes = (size_t)2 * h.nblocks * 4 * 3 * 256 * 8 * sizeof(float);   // (k_resident1: three components per slot)
+    const size_t bytes = (size_t)2 * h.nblocks * 4 * 2 * 256 * 8 * sizeof(float);
     HIPCK(c, hipMalloc(&h.gx, bytes));
     HIPCK(c, hipMemset(h.gx, 0, bytes));
     h.tag = 0;
@@ -1062,17 +688,7 @@ int launch_resident(fdtd_ctx* c, long long step, int nsteps, hipStream_t s) {
     if (c->any_mur) { if (c->have_cpml) RES_LAUNCH(CO, true, true); else RES_LAUNCH(CO, true, false); }                 \
     else { if (c->have_cpml) RES_LAUNCH(CO, false, true); else RES_LAUNCH(CO, false, false); }                          \
   } while (0)
-#define RES1_LAUNCH(CO, MU)                                                                                             \
-  do {                                                                                                                  \
-    if (c->kev0) hipExtLaunchKernelGGL((k_resident1<CO, MU>), grid, block, 0, s, c->kev0, c->kev1, 0, c->p, r);         \
-    else hipLaunchKernelGGL((k_resident1<CO, MU>), grid, block, 0, s, c->p, r);                                         \
-  } while (0)
-  if (h.onehop) {
-    if (coef == 1) { if (c->any_mur) RES1_LAUNCH(1, true); else RES1_LAUNCH(1, false); }
-    else { if (c->any_mur) RES1_LAUNCH(2, true); else RES1_LAUNCH(2, false); }
-  }
-  else if (coef == 0) RES_LAUNCH_C(0); else if (coef == 1) RES_LAUNCH_C(1); else RES_LAUNCH_C(2);
-#undef RES1_LAUNCH
+  if (coef == 0) RES_LAUNCH_C(0); else if (coef == 1) RES_LAUNCH_C(1); else RES_LAUNCH_C(2);
 #undef RES_LAUNCH_C
 #undef RES_LAUNCH
   HIPCK(c, hipGetLastError());

@@ -52,7 +52,7 @@ extern "C" {
 #endif
 
 /* 3: fdtd_p2p_link_info, fdtd_schedule_info; FDTD_FLAG_NO_GRAPH (reserved, unused) removed; fdtd_profile.ms_update_e is per timestep */
-/* 4: FDTD_FLAG_KERNEL_RESIDENT (+ fdtd_schedule_info info[1] = -1 for it, -2 when its tiles exchange halos once per timestep); no entry point added or changed */
+/* 4: FDTD_FLAG_KERNEL_RESIDENT (+ fdtd_schedule_info info[1] = -1 for it); no entry point added or changed */
 #define FDTD_ABI_VERSION 4
 
 enum {
