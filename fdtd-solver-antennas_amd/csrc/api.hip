@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <mutex>
 #include <chrono>
 #include <vector>
 
@@ -106,6 +107,39 @@ int upload_metric_tables(fdtd_ctx* c, const float* emet, const float* hmet) {
   return FDTD_OK;
 }
 
+// Streams outlive contexts: hipStreamCreate takes 3 - 9 ms on this platform (the reference GUI's default call creates a context per run:
+// 12 ms of a 94 ms call went into its two streams).  A SINGLE-SLAB context — nothing it launches ever waits for another context's work —
+// steps on one stream per device shared by all such contexts of the process, and has no communication stream; slabs of a decomposed grid
+// (their kernels wait for each other's halos: they must be able to run side by side) take their own, and a destroyed context hands its
+// (drained) streams to the next one on the same device.
+static std::mutex g_stream_mu;
+static std::vector<hipStream_t> g_stream_pool[64];
+static hipStream_t g_stream_shared[64];
+static hipError_t stream_take(int device, hipStream_t* out) {
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    auto& pool = g_stream_pool[device & 63];
+    if (!pool.empty()) { *out = pool.back(); pool.pop_back(); return hipSuccess; }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+static hipError_t stream_shared(int device, hipStream_t* out) {
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  hipStream_t& s = g_stream_shared[device & 63];
+  if (!s) { const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking); if (e != hipSuccess) { s = nullptr; return e; } }
+  *out = s;
+  return hipSuccess;
+}
+static void stream_give(int device, hipStream_t s) {   // (the caller has synchronised it)
+  if (!s) return;
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    auto& pool = g_stream_pool[device & 63];
+    if (pool.size() < 16) { pool.push_back(s); return; }
+  }
+  hipStreamDestroy(s);
+}
+
 extern "C" {
 
 int fdtd_version(void) { return FDTD_ABI_VERSION; }
@@ -148,8 +182,8 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
     }                                                                                                   \
   } while (0)
   CK(hipSetDevice(d->device));
-  CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  CK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  if (d->world <= 1) { CK(stream_shared(d->device, &c->stream)); c->stream_shared = true; }
+  else { CK(stream_take(d->device, &c->stream)); CK(stream_take(d->device, &c->comm_stream)); }
   CK(hipEventCreateWithFlags(&c->ev_E, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_H, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_haloE, hipEventDisableTiming));
@@ -246,8 +280,8 @@ void fdtd_destroy(fdtd_ctx* c) {
   if (c->ev_H) hipEventDestroy(c->ev_H);
   if (c->ev_haloE) hipEventDestroy(c->ev_haloE);
   if (c->ev_haloH) hipEventDestroy(c->ev_haloH);
-  if (c->stream) hipStreamDestroy(c->stream);
-  if (c->comm_stream) hipStreamDestroy(c->comm_stream);
+  if (!c->stream_shared) stream_give(c->d.device, c->stream);          // (both were synchronised at the top)
+  stream_give(c->d.device, c->comm_stream);
   delete c;
 }
 
@@ -1178,7 +1212,7 @@ int fdtd_run(fdtd_ctx* c, int nsteps) {
   if (p2p_fault) { c->p.p2p_tag_bias = 0u; c->p.p2p_limit = p2p_limit; c->p2p_fault_step = -1; }
   if (r) return r;
   HIPCK(c, hipStreamSynchronize(c->stream));
-  HIPCK(c, hipStreamSynchronize(c->comm_stream));
+  if (c->comm_stream) HIPCK(c, hipStreamSynchronize(c->comm_stream));
   if (c->p.p2p) { r = p2p_check(c); if (r) return r; }
   if ((r = wf_check(c))) return r;
   if ((r = res_check(c))) return r;
@@ -1215,7 +1249,7 @@ int fdtd_run_profiled(fdtd_ctx* c, int nsteps, fdtd_profile* out) {
   if (e == hipSuccess && r == FDTD_OK) {
     e = hipEventRecord(pe.t1, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->comm_stream);
+    if (e == hipSuccess && c->comm_stream) e = hipStreamSynchronize(c->comm_stream);
   }
   if (e == hipSuccess && r == FDTD_OK) {
     float ms = 0.f;
@@ -1740,7 +1774,7 @@ int fdtd_run_linked(fdtd_ctx** ctxs, int n, int nsteps) {
     fdtd_ctx* c = ctxs[r];
     HIPCK(c, hipSetDevice(c->d.device));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    HIPCK(c, hipStreamSynchronize(c->comm_stream));
+    if (c->comm_stream) HIPCK(c, hipStreamSynchronize(c->comm_stream));
     if (int rc = launch_status(c)) return rc;
   }
   return FDTD_OK;

@@ -240,7 +240,8 @@ struct fdtd_ctx {
   // stepping
   int64_t step = 0;
   double* d_energy = nullptr;
-  hipStream_t stream = nullptr, comm_stream = nullptr;
+  hipStream_t stream = nullptr, comm_stream = nullptr;   // (api.hip stream_take / stream_shared: single-slab contexts share one per device)
+  bool stream_shared = false;
   hipEvent_t ev_E = nullptr, ev_H = nullptr, ev_haloE = nullptr, ev_haloH = nullptr;
   bool haloE_pending = false, haloH_pending = false;
   void* comm = nullptr;          // ncclComm_t
