@@ -78,7 +78,8 @@ enum {
                                     unless a neighbour's slab lives on the SAME device (fdtd_p2p_link_info: same_device; several slabs
                                     of one process, or several ranks, on one GPU): the resident blocks of several one-launch kernels
                                     that spin on each other's halos can starve one another on a shared chip.
-                                    Else two launches (three with Mur faces).  Slabs of different size may therefore step under
+                                    Else two launches (Mur faces: the H kernel reads the candidates of the post pass instead of the boundary
+                                    voltages; three only when a voltage probe or an NF2FF box holds a node of a Mur face).  Slabs of different size may therefore step under
                                     different schedules in one run; the results do not depend on it. */
   FDTD_FLAG_KERNEL_DIRECT = 1,   /* the same, named explicitly */
   /* 2..4 were one-pass (fused E+H) variants — per-thread recompute, overlapped LDS tiles, z-marching tiles (round 1), and a
