@@ -378,23 +378,19 @@ __device__ __forceinline__ MurX mur_load_V(const DevParams& p, const int k, cons
                                            float& vz_ip, float& vy_ip, const MurH& m) {
   const unsigned P = (unsigned)p.P, rj = (unsigned)(j * p.P + i0), rk = (unsigned)(k * p.P + i0), xrow = (unsigned)(k * p.ny + j);
   const bool jp = j + 1 < p.ny, kp = k + 1 < p.nk;
-  int zx = -1, zy = -1, zx1 = -1, zy1 = -1;   // z faces: candidate offsets of Vx, Vy for plane k / plane k + 1 (block-uniform)
-  int yz = -1, yx = -1, yz1 = -1, yx1 = -1;   // y faces: of Vz, Vx for row j / row j + 1
+  // (selects, not branches: a face that is off has b = -1, never equal to a plane, row or cell index)
+  // z faces: candidate offsets of Vx, Vy for plane k / plane k + 1 (block-uniform: scalar selects)
+  const int zx = k == m.b[4] ? m.co[4][0] : k == m.b[5] ? m.co[5][0] : -1, zy = k == m.b[4] ? m.co[4][1] : k == m.b[5] ? m.co[5][1] : -1;
+  const int zx1 = k + 1 == m.b[4] ? m.co[4][0] : k + 1 == m.b[5] ? m.co[5][0] : -1, zy1 = k + 1 == m.b[4] ? m.co[4][1] : k + 1 == m.b[5] ? m.co[5][1] : -1;
+  // y faces: of Vz, Vx for row j / row j + 1
+  const bool y2 = j == m.b[2], y3 = j == m.b[3], y2p = j + 1 == m.b[2], y3p = j + 1 == m.b[3];
+  const int yz = y2 ? m.co[2][0] : y3 ? m.co[3][0] : -1, yx = y2 ? m.co[2][1] : y3 ? m.co[3][1] : -1;
+  const int yz1 = y2p ? m.co[2][0] : y3p ? m.co[3][0] : -1, yx1 = y2p ? m.co[2][1] : y3p ? m.co[3][1] : -1;
   MurX x;
-#pragma unroll
-  for (int g = 4; g < 6; ++g) {   // (a face that is off has b = -1: never equal to a plane, row or cell index)
-    if (k == m.b[g]) { zx = m.co[g][0]; zy = m.co[g][1]; }
-    if (k + 1 == m.b[g]) { zx1 = m.co[g][0]; zy1 = m.co[g][1]; }
-  }
-#pragma unroll
-  for (int g = 2; g < 4; ++g) {
-    if (j == m.b[g]) { yz = m.co[g][0]; yx = m.co[g][1]; }
-    if (j + 1 == m.b[g]) { yz1 = m.co[g][0]; yx1 = m.co[g][1]; }
-  }
   // x faces: one of the thread's four cells at most (nx >= 6); its four candidates are loads of their own, issued first
-  int e = -1, cxy = 0, cxz = 0;
-  if (m.b[0] == 0 && i0 == 0) { e = 0; cxy = m.co[0][0]; cxz = m.co[0][1]; }
-  if (m.b[1] >= 0 && (unsigned)(m.b[1] - i0) < 4u) { e = m.b[1] - i0; cxy = m.co[1][0]; cxz = m.co[1][1]; }
+  const bool xlo = m.b[0] == 0 && i0 == 0, xhi = m.b[1] >= 0 && (unsigned)(m.b[1] - i0) < 4u;
+  const int e = xhi ? m.b[1] - i0 : xlo ? 0 : -1;
+  const int cxy = xhi ? m.co[1][0] : m.co[0][0], cxz = xhi ? m.co[1][1] : m.co[0][1];
   const bool xh_ip = m.b[1] >= 0 && i0 + 4 == m.b[1];
   const unsigned o_vx = zx >= 0 ? zx + rj : yx >= 0 ? yx + rk : uo;
   const unsigned o_vy = zy >= 0 ? zy + rj : uo;
