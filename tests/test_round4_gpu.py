@@ -143,3 +143,43 @@ def test_mur_probe_on_a_face_keeps_the_apply_pass(hip_lib, oracle_lib, monkeypat
     assert eh.schedule_info()["launches_per_timestep"] == 3
     assert np.array_equal(eh.fields(), eo.fields())
     assert np.abs(po).max() > 0 and np.abs(ph - po).max() <= 1e-12 * np.abs(po).max()
+
+
+@pytest.mark.parametrize("shape", [(6, 5, 5), (7, 6, 5), (9, 5, 7), (8, 9, 6), (13, 7, 9)])
+@pytest.mark.parametrize("faces", [[1, 1, 1, 1, 1, 1], [1, 0, 0, 1, 1, 0], [0, 1, 1, 0, 0, 1]])
+def test_mur_without_an_apply_pass_on_the_smallest_grids(hip_lib, oracle_lib, monkeypatch, shape, faces):
+    """The smallest grids the two-launch Mur schedule takes (6 x 5 x 5 nodes: a boundary node, its inner neighbour and the opposite face's
+    share one four-cell group, one row, one plane), every node next to a face, seeded fields, through the C ABI: fields identical to
+    the oracle — and to the three-launch sequence."""
+    capi, const = pkg("_capi"), pkg("constants")
+    from opbuild_cases import random_scene
+    monkeypatch.setenv("FDTD_RESIDENT", "0")
+    grid, eps, kap, pec, _ = random_scene(5, shape, False, 3, n_lumped=0, pec_frac=0.0)
+    dt = grid.courant_dt()
+    nx, ny, nz = grid.shape
+    out = []
+    for lib, env in ((hip_lib, None), (hip_lib, "1"), (oracle_lib, None)):
+        if env:
+            monkeypatch.setenv("FDTD_MUR_APPLY_PASS", env)
+        e = capi.Engine(lib, nx, ny, nz, dt, max_steps=64)
+        if env:
+            monkeypatch.delenv("FDTD_MUR_APPLY_PASS")
+        eco = pkg("ecoperator")
+        emet, hmet = eco.pack_metric_tables(*eco.metric_lists(grid, dt), grid)
+        e.build_operator(grid.d, eps, kap, pec, const.EPS0, eco.lumped_overrides(grid, eps, kap, pec, dt, []), emet, hmet)
+        coeff = []
+        for f in range(6):
+            l = grid.lines[f // 2]
+            d = (l[-1] - l[-2]) if f % 2 else (l[1] - l[0])
+            coeff.append((const.C0 * dt - d) / (const.C0 * dt + d))
+        e.set_mur(faces, coeff)
+        e.set_signal(np.zeros(4))
+        seeded_fields(e, 17)
+        for m in (1, 2, 37):
+            e.run(m)
+        out.append(e)
+    e2, e3, eo = out
+    assert e2.schedule_info()["launches_per_timestep"] == 2 and e3.schedule_info()["launches_per_timestep"] == 3
+    fo = eo.fields()
+    assert np.isfinite(fo).all() and np.abs(fo).max() > 0
+    assert np.array_equal(e2.fields(), fo) and np.array_equal(e3.fields(), fo)
