@@ -183,3 +183,46 @@ def test_mur_without_an_apply_pass_on_the_smallest_grids(hip_lib, oracle_lib, mo
     fo = eo.fields()
     assert np.isfinite(fo).all() and np.abs(fo).max() > 0
     assert np.array_equal(e2.fields(), fo) and np.array_equal(e3.fields(), fo)
+
+
+@pytest.mark.parametrize("transport", ["linked", "half_steps"])
+@pytest.mark.parametrize("kinds", [["MUR"] * 6, ["MUR", "PEC", "CPML", "MUR", "MUR", "CPML"]])
+def test_slabs_with_mur_faces_equal_one_slab(hip_lib, monkeypatch, transport, kinds):
+    """Mur faces on a decomposed grid (x / y faces on every slab, z faces on the end slabs): the pre / post / apply launches with their state
+    behind the voltage arrays (round 4 layout) — three slabs coupled by event-ordered peer copies, or stepped half-step by half-step with the
+    halos carried by the host, reproduce ONE slab (two launches per timestep, no apply pass) bit for bit."""
+    capi = pkg("_capi")
+    monkeypatch.setenv("FDTD_RESIDENT", "0")
+    shape, n, world = (50, 46, 33), 180, 3
+    s1 = patch_sim(*shape, boundary=kinds, cpml_cells=5, nr_ts=n)
+    e1 = s1.build(hip_lib)
+    sims = [patch_sim(*shape, boundary=kinds, cpml_cells=5, nr_ts=n) for _ in range(world)]
+    engs = [s.build(hip_lib, rank=r, world=world) for r, s in enumerate(sims)]
+    rng = np.random.default_rng(9)
+    for kind in (0, 1):
+        for comp in range(3):
+            g = (1e-3 * rng.standard_normal(e1.local_shape)).astype(np.float32)
+            e1.set_field(kind, comp, g)
+            for e in engs:
+                e.set_field(kind, comp, np.ascontiguousarray(g[e.k0:e.k0 + e.nk]))
+    e1.run(n)
+    if transport == "linked":
+        for m in (1, 60, n - 61):
+            capi.run_linked(engs, m)
+    else:
+        for r in range(world - 1):       # the H halo of "step -1": the initial fields
+            engs[r + 1].halo_put(capi.HALO_H_UP, engs[r].halo_get(capi.HALO_H_UP))
+        for _ in range(n):
+            for e in engs:
+                e.half_step(capi.PHASE_E)
+            for r in range(world - 1):
+                engs[r].halo_put(capi.HALO_E_DOWN, engs[r + 1].halo_get(capi.HALO_E_DOWN))
+            for e in engs:
+                e.half_step(capi.PHASE_H)
+            for r in range(world - 1):
+                engs[r + 1].halo_put(capi.HALO_H_UP, engs[r].halo_get(capi.HALO_H_UP))
+    f1, f2 = e1.fields(), np.concatenate([e.fields() for e in engs], axis=2)
+    assert np.abs(f1).max() > 0 and np.array_equal(f1, f2)
+    u1 = s1.port_series()[0][0]
+    u2 = sum(s.port_series()[0][0] for s in sims)
+    assert np.abs(u1).max() > 0 and np.abs(u2 - u1).max() <= 1e-12 * np.abs(u1).max()
