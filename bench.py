@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--raw-operator", action="store_true", help="stream 12 coefficient arrays instead of class bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the C3 (HBM-resident) roofline block")
-    ap.add_argument("--no-small-grid-point", action="store_true", help="skip the reference's default GUI scene (resident schedule)")
+    ap.add_argument("--no-small-grid-point", action="store_true", help="skip the side points: the reference's default GUI scene (resident schedule) and its multi-patch default (MUR, two launches)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle timesteps for the cpu_baseline leg (0 = auto)")
     args = ap.parse_args()
 
@@ -236,6 +236,12 @@ def main():
             small_point = small_grid_point(capi, simm, hip)
         except Exception as exc:      # the side point never takes the headline number down with it
             small_point = {"error": f"{type(exc).__name__}: {exc}"}
+    mur_point = None
+    if rank == 0 and world == 1 and not args.no_small_grid_point:
+        try:
+            mur_point = mur_scene_point(hip)
+        except Exception as exc:
+            mur_point = {"error": f"{type(exc).__name__}: {exc}"}
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -256,6 +262,8 @@ def main():
             out["roofline_hbm_resident"] = hbm_point
         if small_point is not None:
             out["small_grid_point"] = small_point
+        if mur_point is not None:
+            out["mur_scene_point"] = mur_point
         if coupling is not None:
             out["multi_gpu"] = coupling
         if cpu is not None:
@@ -372,6 +380,33 @@ def small_grid_point(capi, simm, hip):
             if best is None or rec["value_mcells_s"] > best["value_mcells_s"]:
                 best = rec
     return best
+
+
+def mur_scene_point(hip):
+    """The reference's multi-patch default — prepare_*_microstrip_multi_3d: a 2 x 2 array on a 143x129x89 graded mesh, MUR on all faces
+    (solver_fdtd_openems_microstrip_multi_3d.py:102), four lumped ports of 1 350 edges each — through the plugin path, time stepping only: beyond
+    the resident schedule, two launches per timestep with no Mur apply pass (kernels.hip: mur_load_V).  A side point like small_grid_point."""
+    import tempfile
+    import numpy as np
+    sol = importlib.import_module(PKG + ".solver_fdtd_hip")
+    par = importlib.import_module(PKG + ".params")
+    p = par.PatchAntennaParams.from_user_units(frequency_ghz=2.45, er=4.3, h_mm=1.6, loss_tangent=0.02)
+    arr = [sol.PatchInstance(f"P{n}", p, (ix - 0.5) * 0.0612, (iy - 0.5) * 0.0612, 0.0, sol.FeedDirection.NEG_X)
+           for n, (ix, iy) in enumerate([(0, 0), (1, 0), (0, 1), (1, 1)])]
+    with tempfile.TemporaryDirectory() as td:
+        prep = sol.prepare_hip_microstrip_multi_3d(arr, work_dir=os.path.join(td, "w"), lib=hip)
+        if not prep.ok:
+            return {"error": prep.message}
+        res = sol.run_prepared_hip(prep, frequency_hz=p.frequency_hz, verbose=0)
+        if not res.ok:
+            return {"error": res.message}
+        st = res.stats
+        sched = prep.FDTD.sim.engine.schedule_info()
+        return {"workload": f"reference multi-patch default (multi_3d 2x2): {st['grid'][0]}x{st['grid'][1]}x{st['grid'][2]} graded mesh, MUR, 4 ports",
+                "timesteps": st["steps"], "seconds_stepping": round(st["seconds"], 4), "value_mcells_s": round(st["mcells_per_s"], 1),
+                "us_per_timestep": round(st["seconds"] / max(st["steps"], 1) * 1e6, 3), "energy_db": round(st["energy_db"], 2),
+                "schedule": "resident in registers" if sched["resident"] else f"{sched['launches_per_timestep']} launch(es) per timestep",
+                "algorithmic_bytes_per_timestep": 72 * st["cells"], "Dmax_dBi": round(float(10 * np.log10(res.Dmax)), 3)}
 
 
 def pmc_traffic(workload, kernel, world):
