@@ -190,7 +190,7 @@ int fdtd_create(const fdtd_desc* d, fdtd_ctx** out) {
   CK(hipEventCreateWithFlags(&c->ev_haloH, hipEventDisableTiming));
   const size_t fbytes = (size_t)plane * (d->nk + 2) * sizeof(float);
   // behind every voltage array: room for the Mur candidates of its component (four faces: kernels.hip build_mur_table, mur_load_V)
-  c->mur_tail = 4 * ((size_t)d->ny * P + (size_t)d->nk * P + (size_t)d->nk * d->ny) + 64 + P;   // (cd and st)
+  c->mur_tail = 6 * ((size_t)d->ny * P + (size_t)d->nk * P + (size_t)d->nk * d->ny) + 96 + P;   // (cd twice, and st)
   for (int n = 0; n < 6; ++n) {
     const size_t bytes = fbytes + (n < 3 ? c->mur_tail * sizeof(float) : 0);
     CK(hipMalloc(&c->fieldbase[n], bytes));
@@ -943,9 +943,14 @@ static int p2p_check(fdtd_ctx* c);
 // One launch per timestep (k_step, kernels.hip): single slab, no Mur faces.  AUTO picks it where it measured faster: grids
 // whose fields do not fit the 256 MiB Infinity Cache (there the H sweep finds what the E sweep just touched in that cache
 // instead of in HBM); FDTD_FLAG_KERNEL_WAVEFRONT / $FDTD_WAVEFRONT=1 force it, FDTD_FLAG_KERNEL_DIRECT / =0 forbid it.
+// Mur faces inside the one launch (k_step<..., MUR>): what the two-launch schedule without an apply pass needs (mur_direct_possible), a single slab
+// whose fields fit the Infinity Cache (all E blocks, then all H blocks), and strips of at most 28 blocks (wf_wait_mur polls 9 * nbs flags, one thread each).
+static bool wf_mur_possible(const fdtd_ctx* c) {
+  return c->d.world == 1 && !c->p.p2p && mur_direct_possible(c, false, sources_fusable(c)) && 9 * c->p.nbs <= FDTD_BLOCK && wf_lag_for(c) >= c->d.nk;
+}
 static bool wavefront_possible(const fdtd_ctx* c) {
   // (an H block polls at most 64 flags with one wave: 2 * (1 + P4 / 256) + 3 <= 64, i.e. rows of at most 30 720 cells)
-  return (c->d.world == 1 || c->p.p2p) && !c->any_mur && c->d.nk >= 2 && 2 * (1 + c->p.P4 / FDTD_BLOCK) + 3 <= 64 &&
+  return (c->d.world == 1 || c->p.p2p) && (!c->any_mur || wf_mur_possible(c)) && c->d.nk >= 2 && 2 * (1 + c->p.P4 / FDTD_BLOCK) + 3 <= 64 &&
          (c->p.src_dense_ok || c->src_max_per_strip_plane <= FDTD_BLOCK);   // (sources are always fused into k_step)
 }
 static bool wavefront_active(const fdtd_ctx* c) {
@@ -961,7 +966,9 @@ static bool wavefront_active(const fdtd_ctx* c) {
   // (small grids WITHOUT CPML are the exception: their half-step kernels are so short that the flags cost more than the kernel
   // boundary saves — 200x200x40 without CPML: 83.5 Gcells/s with two launches, 76.5 with one; with CPML 55.6 -> 57.1)
   const size_t blocks = (size_t)c->d.nk * c->p.nstrips * c->p.nbs;   // per sweep
-  if (c->d.world == 1) return big || c->have_cpml || blocks >= 3000;
+  // (re-measured in round 4 with several timesteps per launch, PEC: 128x128x40 (800 blocks) 13.2 us with two launches / 16.9 with one; 200x200x40 (1600) 19.5 / 19.3;
+  //  143x129x89 (1780) 20.1 / 16.8; 167x143x101 (2424) 28.0 / 23.4; 256x256x48 (3360) 37.0 / 32.5; 300x300x60 58.5 / 55.9 — the threshold was 3000)
+  if (c->d.world == 1) return big || c->have_cpml || blocks >= 1700;
   // Slabs that SHARE a device with a neighbour (several contexts of one process on one GPU, or several ranks on one GPU: the test boxes)
   // take two launches: fewer workgroups that can sit resident waiting for another kernel (p2p_pinned_blocks below: one plane's blocks
   // instead of three), i.e. the starvation-freedom condition of p2p_shared_device_ok holds for three times as many slabs.  On its own GPU a
@@ -1072,6 +1079,8 @@ static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   const int multi = wf_multi_max(c);
   const bool sampling = (c->nfreq || c->recorder) && c->nbox && c->every > 0;
   int launches = 0;
+  c->wf_mur = c->any_mur;   // (wavefront_possible has checked that this slab can carry them)
+  if (c->wf_mur && nsteps > 0 && c->mur_pre_step != c->step) launch_mur(c, 0, s);   // the pre pass of the first timestep (later ones: the H blocks)
   for (int n = 0; n < nsteps;) {
     p2p_prime_if_needed(c);
     int chunk = 1;
@@ -1094,6 +1103,7 @@ static int step_loop_wf(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
     ++launches;
   }
   if (pe) pe->launches = launches;
+  if (c->wf_mur && nsteps > 0) c->mur_pre_step = c->step;
   HIPCK(c, hipGetLastError());
   return launch_status(c);
 }
@@ -1125,7 +1135,7 @@ static int step_loop(fdtd_ctx* c, int nsteps, ProfEvents* pe) {
   if (sel > FDTD_FLAG_KERNEL_DIRECT && sel != FDTD_FLAG_KERNEL_WAVEFRONT && sel != FDTD_FLAG_KERNEL_RESIDENT)
     return fdtd_fail(c, FDTD_E_UNSUPPORTED, "kernel selection %u: the one-pass variants were removed (measured slower than the two-pass kernels on every workload)", sel);
   if (sel == FDTD_FLAG_KERNEL_WAVEFRONT && !wavefront_possible(c))
-    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "wavefront schedule: single slab or slabs on the p2p mailbox transport, no Mur faces, at least 2 planes, rows of at most %d cells", 30 * FDTD_BLOCK * 4);
+    return fdtd_fail(c, FDTD_E_UNSUPPORTED, "wavefront schedule: single slab or slabs on the p2p mailbox transport, at least 2 planes, rows of at most %d cells; with Mur faces a single slab within the Infinity Cache, no source edge, voltage probe or NF2FF box on or next to a face", 30 * FDTD_BLOCK * 4);
   if (c->p.p2p) return step_loop_p2p(c, nsteps, pe);
   const bool multi = c->d.world > 1;
   if (resident_active(c)) return step_loop_res(c, nsteps, pe);

@@ -57,11 +57,12 @@ struct MurDevFace {
   float* st[2];          // pre pass: V_inner - coeff * V_boundary (old values); same place and layout as cd
   float* cd[2];          // post pass: st + coeff * V_inner (new values) = the boundary voltage the apply pass stores;
   int co[2], cs;         // it lives behind the voltage array of its component: cd[t] = V[comp[t]] + co[t], row stride cs (P; x faces: ny)
+  int cdn;               // ... twice: the second copy cdn floats behind the first (the one-launch schedule alternates them with the timestep)
   int comp[2];
 };
 // what an H thread needs of the faces to load candidates instead of boundary voltages (kernels.hip mur_load_V): a KERNEL ARGUMENT, so it
 // arrives with the other scalars — read through DevParams::mur it was a memory round trip in front of every wave's first field load
-struct MurH { int b[6]; int co[6][2]; int so[6][2]; float coeff[6]; /* b < 0: face off; co / so: offsets of cd / st from V[comp] */ };
+struct MurH { int b[6]; int co[6][2]; int so[6][2]; int cdn[6]; float coeff[6]; /* b < 0: face off; co / so: offsets of cd / st from V[comp]; cdn: to the second cd copy */ };
 struct MurDev { MurDevFace f[6]; int bnd[6]; /* local boundary index per face, for the priority rule */ };
 
 struct DevParams {
@@ -220,6 +221,7 @@ struct fdtd_ctx {
   bool mur_post_in_E = false;                // this launch of update_E runs the Mur post pass as well (set by phase_E)
   bool mur_no_apply = true;                  // allow the schedule without an apply pass ($FDTD_MUR_APPLY_PASS=1 clears): api.hip mur_direct_possible
   bool mur_direct = false;                   // this timestep: update_H reads the candidates itself and stores them (no k_mur apply launch)
+  bool wf_mur = false;                       // this one-launch run carries Mur faces (k_step<..., MUR>; api.hip step_loop_wf)
   int64_t mur_pre_step = -1;                 // step whose Mur pre pass has already run (inside the previous update_H launch)
   // excitation
   float* sig = nullptr; int nsig = 0;

@@ -182,6 +182,9 @@ __device__ __forceinline__ void sto4_dev(float* base, const unsigned e, const fl
   const v4u_dev t = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
   __builtin_amdgcn_raw_buffer_store_b128(t, dev_buf(base), (int)(e << 2), 0, 16);
 }
+__device__ __forceinline__ void sto1_dev(float* base, const unsigned e, const float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dev_buf(base), (int)(e << 2), 0, 16);
+}
 // Block (k, strip, pb) is done: every wave has its stores acknowledged, the block meets, one lane publishes.
 __device__ __forceinline__ void wf_publish(const DevParams& p, unsigned* flags, const int k, const int strip, const int pb, const unsigned target) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -297,6 +300,21 @@ __device__ __forceinline__ void wf_wait(const DevParams& p, const int k, const i
       if (k + 1 < p.nk) f = p.wf_flags + row + (size_t)p.nstrips * p.nbs + pb;
     }
     if (f) wf_poll(p, f, target);
+  }
+  __syncthreads();
+}
+
+// Mur faces inside the one-launch schedule: an H block also reads CANDIDATES that E blocks wrote — those of the inner nodes, one row / plane away
+// from the boundary nodes it loads (kernels.hip mur_load_V): the row behind it, the whole reach at plane k + 1, plane k - 1 under the upper z face.
+// Waited for generously: every block of strips s - 1 .. s + 1 at planes k - 1 .. k + 1 (9 nbs flags, one thread each; the host takes this schedule only
+// while they fit the workgroup).  All of them are E blocks of the SAME timestep: earlier in dispatch order (all E blocks, then all H blocks).
+__device__ __forceinline__ void wf_wait_mur(const DevParams& p, const int k, const int strip, const unsigned target) {
+  {
+    const int t = (int)threadIdx.x, nbs = p.nbs;
+    const int dk = t / (3 * nbs) - 1, r = t - (dk + 1) * 3 * nbs, ds = r / nbs - 1, q = r - (ds + 1) * nbs;
+    const int kk = k + dk, ss = strip + ds;
+    if (t < 9 * nbs && kk >= 0 && kk < p.nk && ss >= 0 && ss < p.nstrips)
+      wf_poll(p, p.wf_flags + ((size_t)kk * p.nstrips + ss) * nbs + q, target);
   }
   __syncthreads();
 }

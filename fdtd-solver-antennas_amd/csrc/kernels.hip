@@ -53,36 +53,42 @@ struct MurVals { float x0, x1; };
 __device__ __forceinline__ float4 mur_post4(const float c, const float4& v, const float4& s) {   // k_mur mode 1, four cells
   return make_float4(__builtin_fmaf(c, v.x, s.x), __builtin_fmaf(c, v.y, s.y), __builtin_fmaf(c, v.z, s.z), __builtin_fmaf(c, v.w, s.w));
 }
-template <int PHASE>
+// DEV (one-launch schedule): st was written by H blocks of the previous timestep of the same launch and cd is read by H blocks of this
+// timestep on other CUs — device-scope loads, write-through stores; `par` selects the cd copy of this timestep (0 elsewhere).
+template <int PHASE, bool DEV = false>
 __device__ __forceinline__ void mur_post_inline(const DevParams& p, const MurDev& m, const int k, const int j, const int i0, MurVals& mv,
-                                                const float4& vx, const float4& vy, const float4& vz) {
+                                                const float4& vx, const float4& vy, const float4& vz, const int par = 0) {
+  auto ld = [](const float* q, const int o) { return DEV ? ldb4_dev(dev_buf(q), (unsigned)o << 2, 0u) : ld4(q + o); };
+  auto st = [](float* q, const int o, const float4& v) { if (DEV) sto4_dev(q, (unsigned)o, v); else st4(q + o, v); };
 #pragma unroll
   for (int fi = 0; fi < 6; ++fi) {
     const MurDevFace& f = m.f[fi];
     if (!f.on) continue;
-    const int a = fi >> 1;
+    const int a = fi >> 1, pc = par * f.cdn;
     if (a == 2) {          // z faces: tangential x, y; rows j of a plane (block-uniform test)
       if (PHASE == 0 || k != f.in) continue;
       const int o = j * p.P + i0;
-      st4(f.cd[0] + o, mur_post4(f.coeff, vx, ld4(f.st[0] + o)));
-      st4(f.cd[1] + o, mur_post4(f.coeff, vy, ld4(f.st[1] + o)));
+      st(f.cd[0] + pc, o, mur_post4(f.coeff, vx, ld(f.st[0], o)));
+      st(f.cd[1] + pc, o, mur_post4(f.coeff, vy, ld(f.st[1], o)));
     } else if (a == 1) {   // y faces: comp[0] = z, comp[1] = x; one row per plane
       if (PHASE == 0 || j != f.in) continue;
       const int o = k * p.P + i0;
-      st4(f.cd[0] + o, mur_post4(f.coeff, vz, ld4(f.st[0] + o)));
-      st4(f.cd[1] + o, mur_post4(f.coeff, vx, ld4(f.st[1] + o)));
+      st(f.cd[0] + pc, o, mur_post4(f.coeff, vz, ld(f.st[0], o)));
+      st(f.cd[1] + pc, o, mur_post4(f.coeff, vx, ld(f.st[1], o)));
     } else {               // x faces: comp[0] = y, comp[1] = z; [k][j]; one of the thread's four cells at most
       const int e = f.in - i0;
       if (e < 0 || e > 3) continue;
       const int o = k * p.ny + j;
-      if (PHASE == 0) { mv.x0 = f.st[0][o]; mv.x1 = f.st[1][o]; }
-      else {   // four static cases: selecting the component with a computed index sends the vectors through scratch
-        float* const S0 = f.cd[0] + o;
-        float* const S1 = f.cd[1] + o;
-        if (e == 0) { *S0 = __builtin_fmaf(f.coeff, vy.x, mv.x0); *S1 = __builtin_fmaf(f.coeff, vz.x, mv.x1); }
-        if (e == 1) { *S0 = __builtin_fmaf(f.coeff, vy.y, mv.x0); *S1 = __builtin_fmaf(f.coeff, vz.y, mv.x1); }
-        if (e == 2) { *S0 = __builtin_fmaf(f.coeff, vy.z, mv.x0); *S1 = __builtin_fmaf(f.coeff, vz.z, mv.x1); }
-        if (e == 3) { *S0 = __builtin_fmaf(f.coeff, vy.w, mv.x0); *S1 = __builtin_fmaf(f.coeff, vz.w, mv.x1); }
+      if (PHASE == 0) {
+        if (DEV) { mv.x0 = ldb1_dev(dev_buf(f.st[0]), (unsigned)o << 2, 0u); mv.x1 = ldb1_dev(dev_buf(f.st[1]), (unsigned)o << 2, 0u); }
+        else { mv.x0 = f.st[0][o]; mv.x1 = f.st[1][o]; }
+      } else {   // (bit masks: selecting the component with a computed index sends the vectors through scratch)
+        const unsigned m0 = 0u - (unsigned)(e == 0), m1 = 0u - (unsigned)(e == 1), m2 = 0u - (unsigned)(e == 2), m3 = 0u - (unsigned)(e == 3);
+        const float ny_ = __uint_as_float((__float_as_uint(vy.x) & m0) | (__float_as_uint(vy.y) & m1) | (__float_as_uint(vy.z) & m2) | (__float_as_uint(vy.w) & m3));
+        const float nz_ = __uint_as_float((__float_as_uint(vz.x) & m0) | (__float_as_uint(vz.y) & m1) | (__float_as_uint(vz.z) & m2) | (__float_as_uint(vz.w) & m3));
+        const float c0 = __builtin_fmaf(f.coeff, ny_, mv.x0), c1 = __builtin_fmaf(f.coeff, nz_, mv.x1);
+        if (DEV) { sto1_dev(f.cd[0] + pc, (unsigned)o, c0); sto1_dev(f.cd[1] + pc, (unsigned)o, c1); }
+        else { f.cd[0][pc + o] = c0; f.cd[1][pc + o] = c1; }
       }
     }
   }
@@ -161,7 +167,7 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
     vx = ldb4_dev(dev_buf(p.V[0]), bo, 0u); vy = ldb4_dev(dev_buf(p.V[1]), bo, 0u); vz = ldb4_dev(dev_buf(p.V[2]), bo, 0u);
   }
   MurVals mv;
-  if (MUR && valid) mur_post_inline<0>(p, *mur, k, j, i0, mv, vx, vy, vz);   // the S values of the Mur post pass travel with the field loads
+  if (MUR && valid) mur_post_inline<0, WF>(p, *mur, k, j, i0, mv, vx, vy, vz);   // the st values of the x faces travel with the field loads
   // Soft sources inside this strip-plane (block-uniform range; almost always empty).  The range comes by an explicit SCALAR
   // load: left to the compiler this uniform load sits behind the LDS-DMA statements (asm, "memory"), cannot be proven
   // unclobbered and becomes a vector load + s_waitcnt vmcnt(0) in the middle of the load phase — every wave then waited for
@@ -294,7 +300,7 @@ __device__ __forceinline__ void body_E(const DevParams& p, const int strip, cons
     else sto4s(p.nt, p.V[comp], (unsigned)off, v);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (MUR) mur_post_inline<1>(p, *mur, k, j, i0, mv, vx, vy, vz);
+  if (MUR) mur_post_inline<1, WF>(p, *mur, k, j, i0, mv, vx, vy, vz, WF ? (int)(step & 1) : 0);
   if (P2P && k == 0 && p.mb_out_E != nullptr) {   // push the new Vx, Vy of the bottom plane into the lower rank's mailbox
     float* mb = p.mb_out_E + (size_t)(step & 1) * 2 * mb_slot_words(p);
     mb_push(mb, (unsigned)(j * p.P + i0), (unsigned)step + 1u, vx);
@@ -349,8 +355,14 @@ __global__ __launch_bounds__(FDTD_BLOCK, FDTD_E_MINBLOCKS) void k_update_E_mur(c
 // (build_mur_table): rows of stride P for y and z faces — a z face's candidates look like a field plane, a y face's like one row
 // per plane — and [k][j] for x faces.  So a thread that needs a boundary voltage loads the candidate by OFFSET from the same
 // base: no second pointer, and for whole rows / planes no extra load at all (mur_load_V).
+// Element e (run-time) of a vector replaced / read with BIT MASKS: chains of selects on the element index become an insertelement /
+// extractelement with a variable index, which the backend serves from scratch (48 - 64 bytes per lane in the k_step<..., MUR> variants).
+__device__ __forceinline__ float f1_pick(const float old, const float a, const bool take) {
+  const unsigned m = 0u - (unsigned)take;
+  return __uint_as_float(__float_as_uint(old) ^ ((__float_as_uint(old) ^ __float_as_uint(a)) & m));
+}
 __device__ __forceinline__ void f4_put(float4& v, const int e, const float c) {
-  v.x = e == 0 ? c : v.x; v.y = e == 1 ? c : v.y; v.z = e == 2 ? c : v.z; v.w = e == 3 ? c : v.w;
+  v.x = f1_pick(v.x, c, e == 0); v.y = f1_pick(v.y, c, e == 1); v.z = f1_pick(v.z, c, e == 2); v.w = f1_pick(v.w, c, e == 3);
 }
 // The nine voltage loads of an H thread (cells i0..i0+3 of row j in plane k; rows j+1, plane k+1 and cell i0+4 beside them) with
 // every node of a Mur face taken from the candidates.  z faces win over y faces over x faces (the apply order).  Rows, planes
@@ -375,22 +387,26 @@ __device__ __forceinline__ void mur_finish_V(const DevParams& p, const MurH& m, 
 template <bool DEV>
 __device__ __forceinline__ MurX mur_load_V(const DevParams& p, const int k, const int j, const int i0, const unsigned uo, const bool ip_load,
                                            float4& vx, float4& vy, float4& vz, float4& vz_jp, float4& vx_jp, float4& vy_kp, float4& vx_kp,
-                                           float& vz_ip, float& vy_ip, const MurH& m) {
+                                           float& vz_ip, float& vy_ip, const MurH& m, const int par = 0) {
   const unsigned P = (unsigned)p.P, rj = (unsigned)(j * p.P + i0), rk = (unsigned)(k * p.P + i0), xrow = (unsigned)(k * p.ny + j);
+  // (one-launch schedule: the cd copy of this timestep)
+  const int c00 = m.co[0][0] + par * m.cdn[0], c01 = m.co[0][1] + par * m.cdn[0], c10 = m.co[1][0] + par * m.cdn[1], c11 = m.co[1][1] + par * m.cdn[1];
+  const int c20 = m.co[2][0] + par * m.cdn[2], c21 = m.co[2][1] + par * m.cdn[2], c30 = m.co[3][0] + par * m.cdn[3], c31 = m.co[3][1] + par * m.cdn[3];
+  const int c40 = m.co[4][0] + par * m.cdn[4], c41 = m.co[4][1] + par * m.cdn[4], c50 = m.co[5][0] + par * m.cdn[5], c51 = m.co[5][1] + par * m.cdn[5];
   const bool jp = j + 1 < p.ny, kp = k + 1 < p.nk;
   // (selects, not branches: a face that is off has b = -1, never equal to a plane, row or cell index)
   // z faces: candidate offsets of Vx, Vy for plane k / plane k + 1 (block-uniform: scalar selects)
-  const int zx = k == m.b[4] ? m.co[4][0] : k == m.b[5] ? m.co[5][0] : -1, zy = k == m.b[4] ? m.co[4][1] : k == m.b[5] ? m.co[5][1] : -1;
-  const int zx1 = k + 1 == m.b[4] ? m.co[4][0] : k + 1 == m.b[5] ? m.co[5][0] : -1, zy1 = k + 1 == m.b[4] ? m.co[4][1] : k + 1 == m.b[5] ? m.co[5][1] : -1;
+  const int zx = k == m.b[4] ? c40 : k == m.b[5] ? c50 : -1, zy = k == m.b[4] ? c41 : k == m.b[5] ? c51 : -1;
+  const int zx1 = k + 1 == m.b[4] ? c40 : k + 1 == m.b[5] ? c50 : -1, zy1 = k + 1 == m.b[4] ? c41 : k + 1 == m.b[5] ? c51 : -1;
   // y faces: of Vz, Vx for row j / row j + 1
   const bool y2 = j == m.b[2], y3 = j == m.b[3], y2p = j + 1 == m.b[2], y3p = j + 1 == m.b[3];
-  const int yz = y2 ? m.co[2][0] : y3 ? m.co[3][0] : -1, yx = y2 ? m.co[2][1] : y3 ? m.co[3][1] : -1;
-  const int yz1 = y2p ? m.co[2][0] : y3p ? m.co[3][0] : -1, yx1 = y2p ? m.co[2][1] : y3p ? m.co[3][1] : -1;
+  const int yz = y2 ? c20 : y3 ? c30 : -1, yx = y2 ? c21 : y3 ? c31 : -1;
+  const int yz1 = y2p ? c20 : y3p ? c30 : -1, yx1 = y2p ? c21 : y3p ? c31 : -1;
   MurX x;
   // x faces: one of the thread's four cells at most (nx >= 6); its four candidates are loads of their own, issued first
   const bool xlo = m.b[0] == 0 && i0 == 0, xhi = m.b[1] >= 0 && (unsigned)(m.b[1] - i0) < 4u;
   const int e = xhi ? m.b[1] - i0 : xlo ? 0 : -1;
-  const int cxy = xhi ? m.co[1][0] : m.co[0][0], cxz = xhi ? m.co[1][1] : m.co[0][1];
+  const int cxy = xhi ? c10 : c00, cxz = xhi ? c11 : c01;
   const bool xh_ip = m.b[1] >= 0 && i0 + 4 == m.b[1];
   const unsigned o_vx = zx >= 0 ? zx + rj : yx >= 0 ? yx + rk : uo;
   const unsigned o_vy = zy >= 0 ? zy + rj : uo;
@@ -400,8 +416,8 @@ __device__ __forceinline__ MurX mur_load_V(const DevParams& p, const int k, cons
   const unsigned o_vykp = (zy1 >= 0 && kp) ? zy1 + rj : uo + (unsigned)p.plane;
   const unsigned o_vxkp = (zx1 >= 0 && kp) ? zx1 + rj : (yx >= 0 && kp) ? yx + rk + P : uo + (unsigned)p.plane;
   const bool in = i0 + 4 < p.nx;
-  unsigned o_vzip = (in && yz >= 0) ? yz + rk + 4u : xh_ip ? m.co[1][1] + xrow : uo + 4u;
-  unsigned o_vyip = (in && zy >= 0) ? zy + rj + 4u : xh_ip ? m.co[1][0] + xrow : uo + 4u;
+  unsigned o_vzip = (in && yz >= 0) ? yz + rk + 4u : xh_ip ? c11 + xrow : uo + 4u;
+  unsigned o_vyip = (in && zy >= 0) ? zy + rj + 4u : xh_ip ? c10 + xrow : uo + 4u;
   if (!ip_load) o_vzip = o_vyip = (unsigned)__builtin_amdgcn_readfirstlane((int)uo);   // (lane shift: the value comes from the neighbour lane)
   float c_vy = 0.f, c_vz = 0.f, c_vzjp = 0.f, c_vykp = 0.f;
   if (DEV) {
@@ -428,7 +444,10 @@ __device__ __forceinline__ MurX mur_load_V(const DevParams& p, const int k, cons
   return x;
 }
 
-__device__ __forceinline__ float f4_get(const float4& v, const int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+__device__ __forceinline__ float f4_get(const float4& v, const int e) {
+  const unsigned m0 = 0u - (unsigned)(e == 0), m1 = 0u - (unsigned)(e == 1), m2 = 0u - (unsigned)(e == 2), m3 = 0u - (unsigned)(e == 3);
+  return __uint_as_float((__float_as_uint(v.x) & m0) | (__float_as_uint(v.y) & m1) | (__float_as_uint(v.z) & m2) | (__float_as_uint(v.w) & m3));
+}
 __device__ __forceinline__ float4 mur_pre4(const float c, const float4& vb, const float4& vi) {   // k_mur mode 0, four cells
   return make_float4(__builtin_fmaf(-c, vb.x, vi.x), __builtin_fmaf(-c, vb.y, vi.y), __builtin_fmaf(-c, vb.z, vi.z), __builtin_fmaf(-c, vb.w, vi.w));
 }
@@ -438,6 +457,7 @@ __device__ __forceinline__ float4 mur_pre4(const float c, const float4& vb, cons
 // lower face the one on the boundary (its j + 1 / k + 1 neighbour is the inner node), for an upper face the one on the inner
 // node.  As a pass of its own (one thread per face point, 12 rows of blocks behind the main ones) this cost 2.4 / 5.6 / 11.5 us
 // on 200x200x40 / 300x300x60 / 400x400x80; here it is a few stores of the boundary threads.
+template <bool DEV = false>   // DEV (one-launch schedule): the E blocks of the next timestep of the same launch read these: write-through stores
 __device__ __forceinline__ void mur_pre_store(const DevParams& p, const MurH& m, const int k, const int j, const int i0, const unsigned uo,
                                               const float4& vx, const float4& vy, const float4& vz, const float4& vz_jp, const float4& vx_jp,
                                               const float4& vy_kp, const float4& vx_kp, const float vz_ip, const float vy_ip) {
@@ -445,25 +465,27 @@ __device__ __forceinline__ void mur_pre_store(const DevParams& p, const MurH& m,
   return;
 #endif
   const unsigned rj = (unsigned)(j * p.P + i0), rk = (unsigned)(k * p.P + i0), xrow = (unsigned)(k * p.ny + j);
+  auto S4 = [](float* base, const unsigned e, const float4& v) { if (DEV) sto4_dev(base, e, v); else sto4s(0, base, e, v); };
+  auto S1 = [](float* base, const unsigned e, const float v) { if (DEV) sto1_dev(base, e, v); else base[e] = v; };
   // (which faces the thread touches is worked out again rather than kept from mur_load_V: compares against scalars cost less than registers here)
   const bool onz = k == m.b[4] || k == m.b[5], ony = j == m.b[2] || j == m.b[3];
   const bool onx = (m.b[0] == 0 && i0 == 0) || (m.b[1] >= 0 && (unsigned)(m.b[1] - i0) < 4u);
-  if (onz || ony) sto4s(0, p.V[0], uo, vx);
-  if (onz || onx) sto4s(0, p.V[1], uo, vy);
-  if (ony || onx) sto4s(0, p.V[2], uo, vz);
-  if (k == m.b[4]) { sto4s(0, p.V[0], m.so[4][0] + rj, mur_pre4(m.coeff[4], vx, vx_kp)); sto4s(0, p.V[1], m.so[4][1] + rj, mur_pre4(m.coeff[4], vy, vy_kp)); }
-  if (k + 1 == m.b[5]) { sto4s(0, p.V[0], m.so[5][0] + rj, mur_pre4(m.coeff[5], vx_kp, vx)); sto4s(0, p.V[1], m.so[5][1] + rj, mur_pre4(m.coeff[5], vy_kp, vy)); }
-  if (j == m.b[2]) { sto4s(0, p.V[2], m.so[2][0] + rk, mur_pre4(m.coeff[2], vz, vz_jp)); sto4s(0, p.V[0], m.so[2][1] + rk, mur_pre4(m.coeff[2], vx, vx_jp)); }
-  if (j + 1 == m.b[3]) { sto4s(0, p.V[2], m.so[3][0] + rk, mur_pre4(m.coeff[3], vz_jp, vz)); sto4s(0, p.V[0], m.so[3][1] + rk, mur_pre4(m.coeff[3], vx_jp, vx)); }
+  if (onz || ony) S4(p.V[0], uo, vx);
+  if (onz || onx) S4(p.V[1], uo, vy);
+  if (ony || onx) S4(p.V[2], uo, vz);
+  if (k == m.b[4]) { S4(p.V[0], m.so[4][0] + rj, mur_pre4(m.coeff[4], vx, vx_kp)); S4(p.V[1], m.so[4][1] + rj, mur_pre4(m.coeff[4], vy, vy_kp)); }
+  if (k + 1 == m.b[5]) { S4(p.V[0], m.so[5][0] + rj, mur_pre4(m.coeff[5], vx_kp, vx)); S4(p.V[1], m.so[5][1] + rj, mur_pre4(m.coeff[5], vy_kp, vy)); }
+  if (j == m.b[2]) { S4(p.V[2], m.so[2][0] + rk, mur_pre4(m.coeff[2], vz, vz_jp)); S4(p.V[0], m.so[2][1] + rk, mur_pre4(m.coeff[2], vx, vx_jp)); }
+  if (j + 1 == m.b[3]) { S4(p.V[2], m.so[3][0] + rk, mur_pre4(m.coeff[3], vz_jp, vz)); S4(p.V[0], m.so[3][1] + rk, mur_pre4(m.coeff[3], vx_jp, vx)); }
   if (m.b[0] == 0 && i0 == 0) {
-    p.V[1][m.so[0][0] + xrow] = __builtin_fmaf(-m.coeff[0], vy.x, vy.y);
-    p.V[2][m.so[0][1] + xrow] = __builtin_fmaf(-m.coeff[0], vz.x, vz.y);
+    S1(p.V[1], m.so[0][0] + xrow, __builtin_fmaf(-m.coeff[0], vy.x, vy.y));
+    S1(p.V[2], m.so[0][1] + xrow, __builtin_fmaf(-m.coeff[0], vz.x, vz.y));
   }
   const int ei = m.b[1] - 1 - i0;   // the inner node of the upper x face among the thread's cells
   if (m.b[1] >= 0 && (unsigned)ei < 4u) {
     const float by = ei < 3 ? f4_get(vy, ei + 1) : vy_ip, bz = ei < 3 ? f4_get(vz, ei + 1) : vz_ip;
-    p.V[1][m.so[1][0] + xrow] = __builtin_fmaf(-m.coeff[1], by, f4_get(vy, ei));
-    p.V[2][m.so[1][1] + xrow] = __builtin_fmaf(-m.coeff[1], bz, f4_get(vz, ei));
+    S1(p.V[1], m.so[1][0] + xrow, __builtin_fmaf(-m.coeff[1], by, f4_get(vy, ei)));
+    S1(p.V[2], m.so[1][1] + xrow, __builtin_fmaf(-m.coeff[1], bz, f4_get(vz, ei)));
   }
 }
 
@@ -541,7 +563,8 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
       if (staged)
         psi_stage_issue(p, p.psiH, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
     }
-    wf_wait(p, k, strip, pb, wf_target + p.wf_wait_bias);
+    if (MUR) wf_wait_mur(p, k, strip, wf_target + p.wf_wait_bias);   // (the E blocks whose candidates this block loads, too)
+    else wf_wait(p, k, strip, pb, wf_target + p.wf_wait_bias);
     if (MULTI) {
       // Several timesteps per launch: this block's I and psi were written by another workgroup of the SAME launch — the H block
       // of these cells one timestep ago.  That it has finished is only known HERE: the E block of these cells waited for its
@@ -552,6 +575,9 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
       if (staged)
         psi_stage_issue<true>(p, p.psiH, __builtin_amdgcn_readfirstlane(lds_off(s_psi) + (threadIdx.x >> 6) * (PSI_SLOTS * 1024u)), valid, k, j, i0);
     }
+    if (MUR) {
+      mx = mur_load_V<true>(p, k, j, i0, uo, ip_load, vx, vy, vz, vz_jp, vx_jp, vy_kp, vx_kp, vz_ip, vy_ip, *mh, (int)(step & 1));
+    } else {
     const DevRsrc b0 = dev_buf(p.V[0]), b1 = dev_buf(p.V[1]), b2 = dev_buf(p.V[2]);
     const unsigned bo = uo << 2;
     vx = ldb4_dev(b0, bo, 0u); vy = ldb4_dev(b1, bo, 0u); vz = ldb4_dev(b2, bo, 0u);
@@ -560,6 +586,7 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
     {
       const unsigned be = ip_load ? bo : (unsigned)__builtin_amdgcn_readfirstlane((int)bo);
       vz_ip = ldb1_dev(b2, be, 16u); vy_ip = ldb1_dev(b1, be, 16u);
+    }
     }
   }
   if (dep_in) {   // E halo of this step (tag = step + 1)
@@ -573,7 +600,7 @@ __device__ __forceinline__ void body_H(const DevParams& p, const int strip, cons
     const float zn = lane_next(vz.x), yn = lane_next(vy.x);
     if (!ip_load) { vz_ip = zn; vy_ip = yn; }
   }
-  if (MUR && valid) mur_pre_store(p, *mh, k, j, i0, uo, vx, vy, vz, vz_jp, vx_jp, vy_kp, vx_kp, vz_ip, vy_ip);
+  if (MUR && valid) mur_pre_store<WF>(p, *mh, k, j, i0, uo, vx, vy, vz, vz_jp, vx_jp, vy_kp, vx_kp, vz_ip, vy_ip);
   float4 dx1 = sub4(vz, vz_jp), dx2 = sub4(vy, vy_kp);
   float4 dy1 = sub4(vx, vx_kp);
   float4 dy2 = make_float4(vz.x - vz.y, vz.y - vz.z, vz.z - vz.w, vz.w - vz_ip);
@@ -694,10 +721,14 @@ __device__ unsigned long long g_xcd_trace[2 * FDTD_XCD_TRACE_MAX * 4];   // [ste
 // timestep s + 1 start while the H blocks of timestep s drain.  Only the order "all E blocks, then all H blocks" (lag < 0),
 // every timestep in the same direction (an E block waits for the H block of its cells one timestep earlier: half a timestep's
 // blocks back in dispatch order, long finished — walking backwards it would be the block dispatched last).
-template <int COEF, bool PML, bool P2P, bool MULTI = false>
-__global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_MINBLOCKS) void k_step(const DevParams p, const long long step0, const int lag, const unsigned wf_target0,
+// MUR (single slabs, all E blocks then all H blocks): first-order Mur faces inside the launch — the post pass in the E blocks, no apply pass: the H blocks
+// take the boundary voltages from the candidates (two copies alternating with the timestep: an E block of the next timestep must not overwrite what an H
+// block of this one still reads), store them and run the pre pass (mur_load_V, mur_pre_store, wf_wait_mur).
+template <int COEF, bool PML, bool P2P, bool MULTI = false, bool MUR = false>
+__global__ __launch_bounds__(FDTD_BLOCK, (P2P || MUR) ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_MINBLOCKS) void k_step(const DevParams p, const long long step0, const int lag, const unsigned wf_target0,
                                                                         const unsigned nbp, const FastDiv fd_2m, const int down, const unsigned nmain,
-                                                                        const FastDiv fd_per) {
+                                                                        const FastDiv fd_per, const MurDev mur, const MurH mh) {
+  static_assert(!(MUR && P2P), "Mur faces inside one launch: single slabs only");
   extern __shared__ float2 s_lut[];
   __shared__ float4 s_psi[(PML && FDTD_PSI_STAGE) ? FDTD_BLOCK * PSI_SLOTS : 3 * FDTD_BLOCK];   // (the probe blocks borrow it for their reduction; dense sources for their image)
   __shared__ float s_xc[(PML && FDTD_PSI_STAGE) ? 3 * XC_MAX : 1];
@@ -755,8 +786,8 @@ __global__ __launch_bounds__(FDTD_BLOCK, P2P ? FDTD_WF_MINBLOCKS - 1 : FDTD_WF_M
   // 32-byte slot of a per-launch table (two tables, alternating with the step): plain stores, no atomics, no extra barrier
   const unsigned long long t_begin = wall_clock64();
 #endif
-  if (!is_h) body_E<COEF, PML, true, P2P, true, false, MULTI>(p, (int)strip, k, pb, step, s_lut, s_psi, s_xc, s_src, wf_target, nullptr, ts ? wf_target - 1u : 0u);
-  else body_H<COEF == 0, PML, P2P, true, MULTI>(p, (int)strip, k, pb, step, s_psi, s_xc, wf_target, ts ? wf_target - 1u : 0u);
+  if (!is_h) body_E<COEF, PML, true, P2P, true, MUR, MULTI>(p, (int)strip, k, pb, step, s_lut, s_psi, s_xc, s_src, wf_target, MUR ? &mur : nullptr, ts ? wf_target - 1u : 0u);
+  else body_H<COEF == 0, PML, P2P, true, MULTI, MUR>(p, (int)strip, k, pb, step, s_psi, s_xc, wf_target, ts ? wf_target - 1u : 0u, MUR ? &mh : nullptr);
   if (p.xstamp && threadIdx.x == 0) p.xstamp[b] = wall_clock64();   // ... and when this block (its first wave) was done
 #ifdef FDTD_XCD_TRACE
   if (threadIdx.x == 0 && b < FDTD_XCD_TRACE_MAX) {
@@ -1370,16 +1401,33 @@ static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s, in
       int cap_m = c->occ_wf;
       if (c->occ_wf <= 0) {
         const double per_cu = (double)nbp * c->p.nk / (double)chip_cus(c->d.device);     // blocks of one half-step per CU
-        const int cap = per_cu >= 7.0 ? FDTD_WF_MINBLOCKS : std::min(6, (int)per_cu + 1);
+        int cap = per_cu >= 7.0 ? FDTD_WF_MINBLOCKS : std::min(6, (int)per_cu + 1);
+        // (the reference's multi-patch scene — 143x129x89, four lumped ports of 1 350 source edges each: the dense source image, eight probes of as many
+        //  cells — without CPML: 17.7 us per timestep (PEC) / 22.9 (MUR) with 4 or 5 blocks per CU, 19.8 / 26.9 with 6; with CPML 22.8 against 20.0.  The same
+        //  grid with ONE small port: 6 is best for all three.  round 4)
+        if (per_cu < 7.0 && !c->have_cpml && c->src_max_per_strip_plane > SRC_SCAN_MAX) cap = std::min(cap, 5);
         if (cap < FDTD_WF_MINBLOCKS) cap_m = cap;
       }
-      if constexpr (!P2P)
-        launch_main(c, k_step<COEF, PML, false, true>, dim3(per * (unsigned)nsteps), pad, cap_m, s, c->p, step, -1, c->wf_epoch - (unsigned)(nsteps - 1), nbp,
-                    make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), 0, 2u * nE, make_fastdiv(per));
+      if constexpr (!P2P) {
+        if (c->wf_mur)
+          launch_main(c, k_step<COEF, PML, false, true, true>, dim3(per * (unsigned)nsteps), pad, cap_m, s, c->p, step, -1, c->wf_epoch - (unsigned)(nsteps - 1), nbp,
+                      make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), 0, 2u * nE, make_fastdiv(per), c->h_mur, c->h_murh);
+        else
+          launch_main(c, k_step<COEF, PML, false, true>, dim3(per * (unsigned)nsteps), pad, cap_m, s, c->p, step, -1, c->wf_epoch - (unsigned)(nsteps - 1), nbp,
+                      make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), 0, 2u * nE, make_fastdiv(per), c->h_mur, c->h_murh);
+      }
       return;
     }
+    if constexpr (!P2P) {
+      if (c->wf_mur) {
+        launch_main(c, k_step<COEF, PML, false, false, true>, dim3(2u * nE + (unsigned)c->nprobe), pad, c->occ_wf, s, c->p, step, -1, c->wf_epoch, nbp,
+                    make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), down, 2u * nE, make_fastdiv(1u), c->h_mur, c->h_murh);
+        c->p.xstamp = nullptr;
+        return;
+      }
+    }
     launch_main(c, k_step<COEF, PML, P2P>, dim3(2u * nE + (unsigned)c->nprobe), pad, c->occ_wf, s, c->p, step, -1, c->wf_epoch, nbp,
-                make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), down, 2u * nE, make_fastdiv(1u));
+                make_fastdiv((unsigned)c->p.nk * (unsigned)c->p.nbs), down, 2u * nE, make_fastdiv(1u), c->h_mur, c->h_murh);
     c->p.xstamp = nullptr;
     return;
   }
@@ -1388,7 +1436,7 @@ static void launch_step3(fdtd_ctx* c, long long step, int lag, hipStream_t s, in
   const unsigned nmain = 8u * 2u * m * (unsigned)(c->p.nk + lag);
   const dim3 grid(nmain + (unsigned)c->nprobe);
   c->p.xstamp = nullptr;   // (no calibration in this order: the XCD groups advance in step)
-  launch_main(c, k_step<COEF, PML, P2P>, grid, pad, c->occ_wf, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m), down, nmain, make_fastdiv(1u));
+  launch_main(c, k_step<COEF, PML, P2P>, grid, pad, c->occ_wf, s, c->p, step, lag, c->wf_epoch, nbp, make_fastdiv(2u * m), down, nmain, make_fastdiv(1u), c->h_mur, c->h_murh);
 }
 template <int COEF, bool PML>
 static void launch_step2(fdtd_ctx* c, long long step, int lag, hipStream_t s, int nsteps) {
@@ -1518,16 +1566,18 @@ int build_mur_table(fdtd_ctx* c) {
     for (int t = 0; t < 2; ++t) {   // candidates: behind the voltage array of their component (mur_load_V), 16-byte aligned pieces
       const int comp = d.comp[t];
       const size_t n = a == 0 ? (size_t)dim[2] * dim[1] : (size_t)(a == 1 ? dim[2] : dim[1]) * c->p.P;
+      const size_t nr = (n + 3) & ~(size_t)3;
       d.co[t] = (int)tail_next[comp];
       d.cd[t] = c->p.V[comp] + tail_next[comp];
-      tail_next[comp] += (n + 3) & ~(size_t)3;
+      d.cdn = (int)nr;
+      tail_next[comp] += 2 * nr;                   // two copies of cd (one-launch schedule: alternating with the timestep)
       c->h_murh.so[f][t] = (int)tail_next[comp];   // st: same layout, right behind
       d.st[t] = c->p.V[comp] + tail_next[comp];
-      tail_next[comp] += (n + 3) & ~(size_t)3;
+      tail_next[comp] += nr;
     }
     if (d.on && d.du * d.dv > maxpts) maxpts = d.du * d.dv;
   }
-  for (int f = 0; f < 6; ++f) { c->h_murh.b[f] = m.f[f].on ? m.f[f].b : -1; c->h_murh.co[f][0] = m.f[f].co[0]; c->h_murh.co[f][1] = m.f[f].co[1]; c->h_murh.coeff[f] = m.f[f].coeff; }
+  for (int f = 0; f < 6; ++f) { c->h_murh.b[f] = m.f[f].on ? m.f[f].b : -1; c->h_murh.co[f][0] = m.f[f].co[0]; c->h_murh.co[f][1] = m.f[f].co[1]; c->h_murh.coeff[f] = m.f[f].coeff; c->h_murh.cdn[f] = m.f[f].cdn; }
   c->p.mur_nbx = (maxpts + FDTD_BLOCK - 1) / FDTD_BLOCK;
   c->p.mur = nullptr; c->p.mur_nb = 0;
   c->mur_pre_step = -1;

@@ -57,7 +57,7 @@ def draw_case(rng, mur=False):
     cells_max = max(2, min(12, (min(nx, ny, nz) - 8) // 2))
     cells = int(rng.integers(2, cells_max + 1))
     has_mur = "MUR" in kinds
-    sched = str(rng.choice(["auto", "direct", "resident"] if has_mur else ["auto", "direct", "wavefront", "wavefront", "resident"]))
+    sched = str(rng.choice(["auto", "direct", "wavefront", "resident"] if has_mur else ["auto", "direct", "wavefront", "wavefront", "resident"]))
     env = {}
     # round 4: AUTO steps small grids resident in registers; half of the AUTO cases keep the schedules AUTO took before (they still serve
     # every grid that does not fit the chip), and the resident launches are cut short now and then
@@ -254,7 +254,7 @@ def run_batch(ncases, seed, hip, oracle, only=None, log=print, slabs=False, mur=
             log(f"case {n}: skipped ({exc}) {case}")
             continue
         except _mod("_capi").FdtdError as exc:      # an error from the library (a bounded wait that ran out, ...) is a failing case
-            if "(-5): resident schedule" in str(exc):    # ... or a grid the resident schedule, asked for by name, cannot hold
+            if "(-5): resident schedule" in str(exc) or "(-5): wavefront schedule" in str(exc):    # ... or a grid the schedule asked for by name cannot hold
                 log(f"case {n}: refused ({str(exc)[:120]}) {case}")
                 continue
             if "not starvation-free" in str(exc):    # ... except a drawn decomposition the library REFUSES: slabs sharing the test GPU that could pin every workgroup slot

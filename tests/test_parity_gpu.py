@@ -759,8 +759,15 @@ def test_wavefront_schedule_vs_oracle(hip_lib, oracle_lib, shape, bc, use_classe
 
 
 def test_wavefront_schedule_refuses_what_it_cannot_do(hip_lib):
+    """Asked for by name where it cannot run: an error code.  (Mur faces themselves it takes since round 4 — k_step<..., MUR> — but not with a voltage
+    probe on a face: the boundary voltages in memory are not final while the launch runs.)"""
     capi = pkg("_capi")
+    s = patch_sim(40, 40, 30, boundary="MUR", nr_ts=20, nf2ff=False)
+    e = s.build(hip_lib, flags=capi.FLAG_KERNEL_WAVEFRONT)
+    e.run(2)
+    assert e.schedule_info()["launches_per_timestep"] == 1 and not e.schedule_info()["resident"]
     e = patch_sim(40, 40, 30, boundary="MUR", nr_ts=20, nf2ff=False).build(hip_lib, flags=capi.FLAG_KERNEL_WAVEFRONT)
+    e.add_probe(0, np.array([(7 * 40 + 9) * 40 + 0], dtype=np.int64), np.array([1], dtype=np.int8), np.array([1.0], dtype=np.float32))
     with pytest.raises(capi.FdtdError, match="wavefront"):
         e.run(2)
 
@@ -792,8 +799,7 @@ def test_wavefront_schedule_odd_tilings_equal_two_launches(hip_lib, shape, tys, 
 def test_kernel_schedule_selection(hip_lib, monkeypatch):
     """AUTO: small grids (at most two tiles per CU) resident in registers (round 4: fdtd_profile.fused, one launch holds many timesteps);
     beyond that one launch per timestep on single slabs — all E blocks first on cache-resident grids, H a few planes behind E beyond the
-    Infinity Cache — except grids without CPML below 3000 blocks per sweep (two launches) and Mur scenes (three); DIRECT never,
-    WAVEFRONT always (and refused with Mur faces)."""
+    Infinity Cache — except grids without CPML below 1700 blocks per sweep (two launches, Mur faces included); DIRECT never, WAVEFRONT always."""
     capi = pkg("_capi")
     small = patch_sim(64, 60, 36, nr_ts=40, nf2ff=False)
     assert small.build(hip_lib).schedule_info()["resident"] and small.build(hip_lib).run_profiled(4).fused == 1

@@ -162,9 +162,11 @@ def test_auto_takes_the_resident_schedule_for_mur_scenes_only(hip_lib):
     e = patch_sim(300, 300, 60, boundary="MUR", nr_ts=10, nf2ff=False).build(hip_lib, flags=capi.FLAG_KERNEL_RESIDENT)
     with pytest.raises(capi.FdtdError, match="resident schedule"):
         e.run(2)
-    # too many tiles for the chip: AUTO falls back to two launches per timestep (update_E + post, update_H + pre: no apply pass)
+    # too many tiles for the chip: AUTO takes the one-launch schedule (k_step<..., MUR>: from 1700 blocks per sweep), below that two launches
     big = patch_sim(300, 300, 60, boundary="MUR", nr_ts=10, nf2ff=False).build(hip_lib)
-    assert not big.schedule_info()["resident"] and big.schedule_info()["launches_per_timestep"] == 2
+    assert not big.schedule_info()["resident"] and big.schedule_info()["launches_per_timestep"] == 1
+    mid = patch_sim(150, 140, 36, boundary="MUR", nr_ts=10, nf2ff=False).build(hip_lib)
+    assert not mid.schedule_info()["resident"] and mid.schedule_info()["launches_per_timestep"] == 2
 
 
 def test_resident_halo_timeout_heals_itself(hip_lib, monkeypatch):

@@ -107,7 +107,7 @@ def test_mur_without_an_apply_pass_equals_the_apply_pass_and_the_oracle(hip_lib,
         if env:
             monkeypatch.setenv("FDTD_MUR_APPLY_PASS", env)
         s = patch_sim(*shape, boundary=kinds, cpml_cells=5, nr_ts=240, nf2ff_mode="record")
-        e = s.build(lib)
+        e = s.build(lib, flags=pkg("_capi").FLAG_KERNEL_DIRECT if lib is hip_lib else 0)   # (AUTO would take ONE launch where there are CPML layers too)
         if env:
             monkeypatch.delenv("FDTD_MUR_APPLY_PASS")
         seeded_fields(e, 11)
@@ -226,3 +226,32 @@ def test_slabs_with_mur_faces_equal_one_slab(hip_lib, monkeypatch, transport, ki
     u1 = s1.port_series()[0][0]
     u2 = sum(s.port_series()[0][0] for s in sims)
     assert np.abs(u1).max() > 0 and np.abs(u2 - u1).max() <= 1e-12 * np.abs(u1).max()
+
+
+@pytest.mark.parametrize("shape", [(48, 44, 30), (61, 37, 23), (132, 70, 26), (150, 140, 36)])
+@pytest.mark.parametrize("kinds", [["MUR"] * 6, ["MUR", "PEC", "CPML", "MUR", "MUR", "CPML"]])
+@pytest.mark.parametrize("multi", ["64", "1", "3"])
+def test_mur_inside_the_one_launch_schedule_equals_the_oracle(hip_lib, oracle_lib, monkeypatch, shape, kinds, multi):
+    """Mur faces inside k_step (one launch per timestep / several timesteps per launch): post pass in the E blocks, candidates read by the H blocks
+    behind the flags of every E block that wrote one (wf_wait_mur), two candidate copies alternating with the timestep, pre pass and write-back by
+    the H blocks with write-through stores.  Fields bit for bit, port series and recorded NF2FF faces against the oracle; cut launches."""
+    capi = pkg("_capi")
+    monkeypatch.setenv("FDTD_RESIDENT", "0")
+    monkeypatch.setenv("FDTD_WF_MULTI", multi)
+    out = []
+    for lib in (hip_lib, oracle_lib):
+        s = patch_sim(*shape, boundary=kinds, cpml_cells=5, nr_ts=260, nf2ff_mode="record")
+        e = s.build(lib, flags=capi.FLAG_KERNEL_WAVEFRONT if lib is hip_lib else 0)
+        seeded_fields(e, 21)
+        for n in (1, 2, 90, 150):
+            e.run(n)
+        out.append((s, e))
+    (sh, eh), (so, eo) = out
+    info = eh.schedule_info()
+    assert info["launches_per_timestep"] == 1 and not info["resident"]
+    fh, fo = eh.fields(), eo.fields()
+    assert np.abs(fo).max() > 0 and np.array_equal(fh, fo)
+    for (ua, ia), (ub, ib) in zip(sh.port_series(), so.port_series()):
+        assert np.allclose(ua, ub, rtol=0, atol=1e-12 * np.abs(ub).max()) and np.allclose(ia, ib, rtol=0, atol=1e-12 * np.abs(ib).max())
+    for a, b in zip(sh.nf2ff_boxes(), so.nf2ff_boxes()):
+        assert np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-9 * np.abs(b).max()
