@@ -71,14 +71,14 @@ enum { FDTD_HALO_H_UP = 0, FDTD_HALO_E_DOWN = 1 };   /* Ix,Iy top plane -> rank+
 /* Kernel selection (fdtd_desc.flags). */
 enum {
   FDTD_FLAG_KERNEL_AUTO   = 0,   /* the schedule measured faster (fdtd_schedule_info tells which one a context took).  One launch per
-                                    timestep (WAVEFRONT below) where it is possible — no Mur faces, at least 2 planes, rows of at most
+                                    timestep (WAVEFRONT below) where it is possible — at least 2 planes, rows of at most
                                     30 720 cells — AND: on a single slab, when the fields exceed the 256 MiB Infinity Cache, or the slab
-                                    has CPML layers, or a sweep has >= 3000 blocks of 1024 cells; on a slab of a decomposed grid (p2p
+                                    has CPML layers, or a sweep has >= 1700 blocks of 1024 cells (Mur faces: single slabs within the cache); on a slab of a decomposed grid (p2p
                                     mailbox transport only), when the fields exceed the Infinity Cache or a sweep has >= 1800 blocks —
                                     unless a neighbour's slab lives on the SAME device (fdtd_p2p_link_info: same_device; several slabs
                                     of one process, or several ranks, on one GPU): the resident blocks of several one-launch kernels
                                     that spin on each other's halos can starve one another on a shared chip.
-                                    Else two launches (Mur faces: the H kernel reads the candidates of the post pass instead of the boundary
+                                    Else two launches (Mur faces: the H kernel — like the H blocks of the one launch — reads the candidates of the post pass instead of the boundary
                                     voltages; three only when a voltage probe or an NF2FF box holds a node of a Mur face).  Slabs of different size may therefore step under
                                     different schedules in one run; the results do not depend on it. */
   FDTD_FLAG_KERNEL_DIRECT = 1,   /* the same, named explicitly */
@@ -87,7 +87,8 @@ enum {
      passes (profiles/r01, profiles/r02/one_pass_*); none ships: selecting them is FDTD_E_UNSUPPORTED. */
   FDTD_FLAG_KERNEL_WAVEFRONT = 5, /* ONE launch per timestep: the E sweep runs a few planes ahead of the H sweep, coupled by per-block
                                     flags, so that H reads what E just touched from the Infinity Cache instead of HBM.  Single slab, or
-                                    slabs on the p2p mailbox transport; no Mur faces (else FDTD_E_UNSUPPORTED).  Below 256 MiB of fields all E blocks
+                                    slabs on the p2p mailbox transport; Mur faces on single slabs whose fields fit the Infinity Cache, with no source edge, voltage probe or
+                                    NF2FF box on or next to a face (else FDTD_E_UNSUPPORTED).  Below 256 MiB of fields all E blocks
                                     run first, then all H blocks — and on a single slab ONE launch then holds SEVERAL timesteps (up to 64,
                                     cut at the timesteps whose NF2FF faces are sampled; fdtd_schedule_info info[7]): no kernel boundary, the E
                                     blocks of the next timestep start while the H blocks of this one drain.  DIRECT never takes it.

@@ -40,16 +40,25 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in acc.items():
         raw[k][ctr] = {"launches": len(v), "mean": sum(v) / len(v)}
 per = {}
-# launches of k_step<.., true> hold several timesteps: their traffic per TIMESTEP = per launch / (timesteps they stepped / launches)
-single = sum(v["FETCH_SIZE"]["launches"] for k, v in raw.items() if "k_step" in k and k.rstrip().endswith("false>") and "FETCH_SIZE" in v)
+
+
+def holds_several_timesteps(k):   # k_step<COEF, PML, P2P, MULTI, MUR>: the fourth template argument
+    if "k_step<" not in k:
+        return False
+    a = [x.strip() for x in k[k.index("<") + 1:k.rindex(">")].split(",")]
+    return len(a) >= 4 and a[3] == "true"
+
+
+# launches of k_step<.., MULTI = true, ..> hold several timesteps: their traffic per TIMESTEP = per launch / (timesteps they stepped / launches)
+single = sum(v["FETCH_SIZE"]["launches"] for k, v in raw.items() if "k_step" in k and not holds_several_timesteps(k) and "FETCH_SIZE" in v)
 for k, v in raw.items():
     if ("k_update" in k or "k_step" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         rd = v["FETCH_SIZE"]["mean"] * 1024.0 * 2.0      # KiB, x2 gfx950 correction
         wr = v["WRITE_SIZE"]["mean"] * 1024.0
         per[k] = {"read_bytes_corrected": rd, "write_bytes": wr, "total_bytes": rd + wr}
-        if "k_step" in k and k.rstrip().endswith("true>") and timesteps_total:
+        if holds_several_timesteps(k) and timesteps_total:
             tsl = (timesteps_total - single) / v["FETCH_SIZE"]["launches"]
             per[k].update({"timesteps_per_launch": tsl, "total_bytes_per_timestep": (rd + wr) / tsl})
-json.dump({"raw": raw, "per_launch_traffic": per, "workload": wl,
+json.dump({"raw": raw, "per_launch_traffic": per, "workload": wl, "timesteps_total": timesteps_total,
            "note": "separate --pmc passes; FETCH_SIZE x2 (gfx950 correction); KiB units; tools/pmc_traffic.py"}, open(out, "w"), indent=1)
 print(json.dumps(per, indent=1))
