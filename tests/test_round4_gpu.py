@@ -255,3 +255,27 @@ def test_mur_inside_the_one_launch_schedule_equals_the_oracle(hip_lib, oracle_li
         assert np.allclose(ua, ub, rtol=0, atol=1e-12 * np.abs(ub).max()) and np.allclose(ia, ib, rtol=0, atol=1e-12 * np.abs(ib).max())
     for a, b in zip(sh.nf2ff_boxes(), so.nf2ff_boxes()):
         assert np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-9 * np.abs(b).max()
+
+
+def test_microstrip_3d_mur_scene_one_launch_gpu_vs_oracle(hip_lib, oracle_lib, tmp_path):
+    """The reference's 3-D microstrip patch at 5.8 GHz with its default MUR faces (167x143x101: beyond the resident schedule and above 1700 blocks
+    per sweep, i.e. Mur faces INSIDE the one-launch schedule) through the plugin surface, 900 timesteps, on the HIP library and on the oracle:
+    port series identical, S11 and pattern cuts within 1e-3 (tests/acceptance_mur_scenes.py runs it to its end: profiles/r04)."""
+    s = pkg("solver_fdtd_hip")
+    P = pkg("params").PatchAntennaParams
+    p = P.from_user_units(frequency_ghz=5.8, er=4.3, h_mm=1.6, loss_tangent=0.02)
+    out = []
+    for lib, tag in ((hip_lib, "gpu"), (oracle_lib, "cpu")):
+        prep = s.prepare_hip_microstrip_patch_3d(p, work_dir=str(tmp_path / tag), lib=lib)
+        assert prep.ok, prep.message
+        prep.FDTD.NrTS = 900
+        r = s.run_prepared_hip(prep, frequency_hz=5.8e9, verbose=0)
+        assert r.ok, r.message
+        info = prep.FDTD.sim.engine.schedule_info() if lib is hip_lib else None
+        out.append((r, prep.FDTD.sim.port_series()[0], s.s11_from_port(prep.port, prep.sim_path, 5.8e9)[1], info))
+    (g, sg, s11g, info), (c, sc_, s11c, _) = out
+    assert info["launches_per_timestep"] == 1 and not info["resident"]
+    assert g.stats["grid"] == c.stats["grid"] and g.stats["steps"] == c.stats["steps"] == 900
+    assert np.abs(sc_[0]).max() > 0 and np.array_equal(sg[0], sc_[0]) and np.array_equal(sg[1], sc_[1])
+    assert np.linalg.norm(s11g - s11c) <= 1e-3 * np.linalg.norm(s11c)
+    assert np.linalg.norm(g.intensity - c.intensity) <= 1e-3 * np.linalg.norm(c.intensity)
