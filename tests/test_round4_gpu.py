@@ -279,3 +279,29 @@ def test_microstrip_3d_mur_scene_one_launch_gpu_vs_oracle(hip_lib, oracle_lib, t
     assert np.abs(sc_[0]).max() > 0 and np.array_equal(sg[0], sc_[0]) and np.array_equal(sg[1], sc_[1])
     assert np.linalg.norm(s11g - s11c) <= 1e-3 * np.linalg.norm(s11c)
     assert np.linalg.norm(g.intensity - c.intensity) <= 1e-3 * np.linalg.norm(c.intensity)
+
+
+def test_mur_one_launch_flag_timeout_heals_itself(hip_lib, monkeypatch):
+    """The bounded flag waits of the one-launch schedule with Mur faces (wf_wait_mur / wf_wait): under the fault hook (the H blocks of timestep 37 wait
+    for a flag value nobody publishes, limit 20 us) the C ABI reports FDTD_E_DEVICE, and Simulation.run repeats the run under two launches per
+    timestep — same fields and port series as a run that took two launches from the start."""
+    capi = pkg("_capi")
+    monkeypatch.setenv("FDTD_RESIDENT", "0")
+    ref = patch_sim(132, 70, 26, boundary="MUR", nr_ts=300)
+    e = ref.build(hip_lib, flags=capi.FLAG_KERNEL_DIRECT)
+    ref.run(check_every=100)
+    f_ref = e.fields()
+    monkeypatch.setenv("FDTD_WF_FAULT_STEP", "37")
+    s = patch_sim(132, 70, 26, boundary="MUR", nr_ts=300)
+    eng = s.build(hip_lib, flags=capi.FLAG_KERNEL_WAVEFRONT)
+    assert eng.schedule_info()["launches_per_timestep"] == 1
+    with pytest.raises(capi.FdtdError, match="wavefront schedule"):
+        eng.run(100)
+    s = patch_sim(132, 70, 26, boundary="MUR", nr_ts=300)
+    s.build(hip_lib, flags=capi.FLAG_KERNEL_WAVEFRONT)
+    logs = []
+    st = s.run(check_every=100, log=logs.append)
+    assert st.schedule_fallback and "wavefront schedule" in st.schedule_fallback and logs
+    assert st.steps == 300 and s.engine.schedule_info()["launches_per_timestep"] == 2
+    assert np.array_equal(s.engine.fields(), f_ref)
+    assert np.array_equal(s.port_series()[0][0], ref.port_series()[0][0])
